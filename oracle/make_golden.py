@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference in the build container.
+
+Runs only where ``/root/reference`` exists (never on the GPU box).  It imports
+the reference package from its read-only location under an alias module name
+(so it can coexist with this repo's own packages), feeds it seeded inputs and
+stores inputs + outputs as small ``.npz`` fixtures.  Nothing of the reference's
+source is copied; the fixtures are data only.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixture families:
+  G1  the reference's own test grid (tests/test_functional.py:11-20), thinned
+  G2  multi-channel groups, per-axis hyper-parameters, the four padding modes
+  G3  the BASELINE.json configs: seed, input checksum, sampled outputs
+"""
+from __future__ import annotations
+
+import importlib.util
+import itertools
+import os
+import sys
+import warnings
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF_ROOT = "/root/reference/fft_conv_pytorch"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location(
+        "_reference_fft_conv_pytorch", os.path.join(REF_ROOT, "__init__.py"),
+        submodule_search_locations=[REF_ROOT])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def seeded(seed, *shape):
+    return np.random.default_rng(seed).standard_normal(shape, dtype=np.float32)
+
+
+def make_inputs(seed, batch, cin, cout, groups, spatial, ksize):
+    x = seeded(seed, batch, cin, *spatial)
+    w = seeded(seed + 1, cout, cin // groups, *ksize)
+    b = seeded(seed + 2, cout)
+    return x, w, b
+
+
+def run_ref(ref, x, w, b, **kw):
+    import torch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = ref.functional.fft_conv(torch.from_numpy(x), torch.from_numpy(w),
+                                    bias=None if b is None else torch.from_numpy(b), **kw)
+    return y.contiguous().numpy()
+
+
+def g1_cases():
+    """Thinned copy of the reference grid: every value of every axis appears."""
+    grid = itertools.product([1, 2, 3], [7, 8], [2, 3], [2, 3], [1, 2, 3], [2, 3], [0, 1], [1, 2], [1, 2])
+    cases = []
+    for idx, (nd, size, cin, cout, groups, k, pad, stride, dil) in enumerate(grid):
+        g = np.gcd(cin, np.gcd(cout, groups))
+        if idx % 7 not in (0, 3) and not (nd == 1 and idx % 2 == 0):
+            continue
+        if nd == 3 and idx % 21 != 0:
+            continue
+        cases.append(dict(ndim=nd, size=size, cin=cin, cout=cout, groups=int(g), k=k,
+                          padding=pad, stride=stride, dilation=dil))
+    return cases
+
+
+def g2_cases():
+    return [
+        dict(batch=2, cin=8, cout=8, groups=2, spatial=(257,), k=(9,), stride=1, padding=4, dilation=1, mode="constant"),
+        dict(batch=1, cin=64, cout=64, groups=8, spatial=(4096,), k=(33,), stride=1, padding=0, dilation=4, mode="constant"),
+        dict(batch=3, cin=6, cout=4, groups=2, spatial=(100,), k=(7,), stride=3, padding=5, dilation=2, mode="reflect"),
+        dict(batch=2, cin=4, cout=6, groups=1, spatial=(64,), k=(5,), stride=2, padding=3, dilation=1, mode="replicate"),
+        dict(batch=2, cin=5, cout=3, groups=1, spatial=(50,), k=(4,), stride=1, padding=6, dilation=3, mode="circular"),
+        dict(batch=2, cin=4, cout=4, groups=2, spatial=(20, 33), k=(3, 5), stride=(1, 2), padding=(2, 1), dilation=(2, 1), mode="constant"),
+        dict(batch=1, cin=3, cout=5, groups=1, spatial=(31, 18), k=(4, 3), stride=(2, 1), padding=(1, 2), dilation=(1, 2), mode="reflect"),
+        dict(batch=2, cin=2, cout=2, groups=1, spatial=(16, 16), k=(5, 5), stride=1, padding=2, dilation=1, mode="circular"),
+        dict(batch=2, cin=2, cout=4, groups=2, spatial=(16, 17), k=(3, 3), stride=1, padding=1, dilation=1, mode="replicate"),
+        dict(batch=1, cin=4, cout=2, groups=2, spatial=(9, 12, 10), k=(2, 3, 4), stride=(1, 2, 1), padding=(1, 0, 2), dilation=(2, 1, 1), mode="constant"),
+        dict(batch=2, cin=3, cout=3, groups=3, spatial=(8, 8, 8), k=(3, 3, 3), stride=1, padding=1, dilation=1, mode="replicate"),
+        dict(batch=1, cin=2, cout=3, groups=1, spatial=(10, 9, 11), k=(3, 2, 3), stride=2, padding=(2, 1, 2), dilation=1, mode="circular"),
+        dict(batch=1, cin=2, cout=2, groups=1, spatial=(12, 10, 9), k=(2, 2, 2), stride=1, padding=1, dilation=2, mode="reflect"),
+        # long 1D rows: several overlap-save tiles in the HIP path
+        dict(batch=2, cin=8, cout=8, groups=1, spatial=(9000,), k=(300,), stride=1, padding=0, dilation=1, mode="constant"),
+        dict(batch=1, cin=3, cout=5, groups=1, spatial=(5000,), k=(129,), stride=2, padding=64, dilation=1, mode="reflect"),
+        dict(batch=1, cin=16, cout=24, groups=1, spatial=(3000,), k=(65,), stride=1, padding=32, dilation=1, mode="constant"),
+    ]
+
+
+BASELINE_CONFIGS = {
+    # name: (batch, cin, cout, groups, spatial, kernel, dilation)   -- SURVEY.md section 8d
+    "cfg0": (1, 8, 8, 1, (32768,), (128,), 1),
+    "cfgA": (32, 8, 8, 1, (32768,), (512,), 1),
+    "cfgB": (16, 8, 8, 1, (512, 512), (31, 31), 1),
+    "cfgC": (8, 8, 8, 1, (64, 64, 64), (9, 9, 9), 1),
+    "cfgD_b1": (1, 64, 64, 8, (1 << 20,), (257,), 4),   # one batch item of cfgD
+}
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    ref = load_reference()
+
+    # ---- G1
+    store = {}
+    cases = g1_cases()
+    for n, c in enumerate(cases):
+        nd = c["ndim"]
+        x, w, b = make_inputs(1000 + 3 * n, 2, c["cin"], c["cout"], c["groups"],
+                              (c["size"],) * nd, (c["k"],) * nd)
+        y = run_ref(ref, x, w, b, stride=c["stride"], padding=c["padding"],
+                    dilation=c["dilation"], groups=c["groups"])
+        store[f"x{n}"], store[f"w{n}"], store[f"b{n}"], store[f"y{n}"] = x, w, b, y
+        store[f"p{n}"] = np.array([nd, c["size"], c["cin"], c["cout"], c["groups"], c["k"],
+                                   c["padding"], c["stride"], c["dilation"]], dtype=np.int64)
+    store["count"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT_DIR, "g1_reference_grid.npz"), **store)
+    print("G1:", len(cases), "cases")
+
+    # ---- G2
+    store = {}
+    cases = g2_cases()
+    for n, c in enumerate(cases):
+        x, w, b = make_inputs(5000 + 3 * n, c["batch"], c["cin"], c["cout"], c["groups"],
+                              c["spatial"], c["k"])
+        y = run_ref(ref, x, w, b, stride=c["stride"], padding=c["padding"],
+                    dilation=c["dilation"], groups=c["groups"], padding_mode=c["mode"])
+        big = x.size > 200000 or y.size > 200000
+        if big:   # keep the seed, a checksum and samples only
+            idx = np.random.default_rng(77 + n).integers(0, y.size, 4096)
+            store[f"yi{n}"], store[f"ys{n}"] = idx, y.reshape(-1)[idx]
+            store[f"ysum{n}"] = np.array(y.astype(np.float64).sum())
+            store[f"xsum{n}"] = np.array(x.astype(np.float64).sum())
+            store[f"yshape{n}"] = np.array(y.shape)
+        else:
+            store[f"x{n}"], store[f"w{n}"], store[f"b{n}"], store[f"y{n}"] = x, w, b, y
+        nd = len(c["spatial"])
+        meta = dict(c)
+        meta["seed"] = 5000 + 3 * n
+        meta["big"] = bool(big)
+        store[f"meta{n}"] = np.array(repr(meta))
+    store["count"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT_DIR, "g2_extended.npz"), **store)
+    print("G2:", len(cases), "cases")
+
+    # ---- G3
+    store = {}
+    for name, (batch, cin, cout, groups, spatial, ksize, dil) in BASELINE_CONFIGS.items():
+        seed = 9000 + sum(map(ord, name))
+        x, w, b = make_inputs(seed, batch, cin, cout, groups, spatial, ksize)
+        y = run_ref(ref, x, w, b, dilation=dil, groups=groups)
+        idx = np.random.default_rng(seed + 5).integers(0, y.size, 4096)
+        store[f"{name}_seed"] = np.array(seed)
+        store[f"{name}_xsum"] = np.array(x.astype(np.float64).sum())
+        store[f"{name}_x64"] = x.reshape(-1)[:64].copy()
+        store[f"{name}_yshape"] = np.array(y.shape)
+        store[f"{name}_yidx"] = idx
+        store[f"{name}_ysamp"] = y.reshape(-1)[idx]
+        store[f"{name}_ysum"] = np.array(y.astype(np.float64).sum())
+        store[f"{name}_yabsmax"] = np.array(np.abs(y).max())
+        print("G3:", name, y.shape, "absmax", float(np.abs(y).max()))
+        del x, y
+    np.savez_compressed(os.path.join(OUT_DIR, "g3_baseline_configs.npz"), **store)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""The oracle (oracle/fft_conv_oracle.py) against the golden vectors produced by the real
+reference (oracle/make_golden.py) and against an FFT-free float64 direct convolution."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fft_conv_oracle as orc
+from tests import golden_util as gu
+
+REL_TOL = 1e-4      # north_star: outputs within 1e-4 rel fp32
+TIGHT = 2e-5        # oracle backends vs the reference itself: same algorithm, fp32
+
+
+def test_ntuple_matches_reference_semantics():
+    assert orc.ntuple(3, 2) == (3, 3)
+    assert orc.ntuple([1, 2, 3], 3) == (1, 2, 3)
+    with pytest.raises(ValueError, match="Cannot cast tuple of length 2 to length 3."):
+        orc.ntuple((1, 2), 3)
+    with pytest.raises(ValueError, match="Cannot cast tuple of length 4 to length 1."):
+        orc.ntuple("same", 1)   # a str is Iterable: reference quirk
+
+
+def test_oracle_backends_match_reference_grid_g1():
+    worst = 0.0
+    for n, x, w, b, kw, y_ref in gu.g1_cases():
+        y_t = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+        y_n = orc.fft_conv_oracle_numpy(x, w, b, **kw)
+        y_d = orc.direct_conv_float64(x, w, b, **kw)
+        worst = max(worst, gu.check_against(y_t, y_ref, TIGHT), gu.check_against(y_n, y_ref, TIGHT),
+                    gu.check_against(y_d, y_ref, TIGHT))
+        # the reference's own absolute tolerance (benchmark_utils.py:53-57) holds at these sizes
+        assert np.abs(y_t - y_d).max() < 1e-4 and np.abs(y_t - y_d).mean() < 5e-5
+    assert worst < TIGHT
+
+
+def test_oracle_backends_match_extended_g2():
+    for n, x, w, b, kw, gold in gu.g2_cases():
+        y_t = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+        gu.check_against(y_t, gold, TIGHT)
+        if x.size < 50000:
+            gu.check_against(orc.fft_conv_oracle_numpy(x, w, b, **kw), gold, TIGHT)
+            gu.check_against(orc.direct_conv_float64(x, w, b, **kw), gold, TIGHT)
+
+
+@pytest.mark.parametrize("name", ["cfg0", "cfgA"])
+def test_oracle_matches_baseline_config_samples_g3(name):
+    x, w, b, kw, gold = gu.g3_case(name)
+    y = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+    gu.check_against(y, gold, TIGHT)
+
+
+def test_any_longer_fft_gives_same_valid_outputs():
+    """Freedom (1) of SURVEY section 0: padding the signal with trailing zeros (= a longer FFT)
+    leaves the valid outputs unchanged -- the HIP path relies on this (power-of-two tiles)."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 3, 50), dtype=np.float32)
+    w = rng.standard_normal((4, 3, 7), dtype=np.float32)
+    y = orc.fft_conv_oracle_numpy(x, w)
+    x_long = np.concatenate([x, np.zeros((2, 3, 78), np.float32)], axis=-1)
+    y_long = orc.fft_conv_oracle_numpy(x_long, w)[..., : y.shape[-1]]
+    assert orc.rel_err(y_long, y) < 1e-5
+
+
+def test_output_extent_formula():
+    for size, k, s, p, d in [(7, 2, 1, 0, 1), (8, 3, 2, 1, 2), (32768, 512, 1, 0, 1), (100, 7, 3, 5, 2)]:
+        y = torch.nn.functional.conv1d(torch.zeros(1, 1, size), torch.zeros(1, 1, k), stride=s, padding=p, dilation=d)
+        assert orc.output_extent(size, k, s, p, d) == y.shape[-1]

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: forward FFT convolution throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfgA]
+
+A "step" is one forward pass of the hot path (FFTConv1d.forward, kernel spectrum
+cached per weight version as the module does) over one synthetic batch that is
+already resident in HBM.  Steps rotate over several distinct input/output
+buffer sets whose total size exceeds the 256 MiB Infinity Cache, so every step
+streams its input from HBM instead of re-reading a cache-resident copy.  The
+steps are captured into a HIP graph (one rotation per graph) to keep the host
+out of the timed region; every captured step is a full launch.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL); each rank
+convolves its own batch shard of the same size (weak scaling); the only
+collective is the one-off broadcast of the weights from rank 0.  The timed
+region is bracketed by barrier + synchronize and the max over ranks is taken.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# name: (ndim, batch, cin, cout, groups, spatial, kernel, dilation)  -- SURVEY.md section 8d
+CONFIGS = {
+    "cfg0": (1, 1, 8, 8, 1, (32768,), (128,), 1),
+    "cfgA": (1, 32, 8, 8, 1, (32768,), (512,), 1),
+    "cfgB": (2, 16, 8, 8, 1, (512, 512), (31, 31), 1),
+    "cfgC": (3, 8, 8, 8, 1, (64, 64, 64), (9, 9, 9), 1),
+    "cfgD": (1, 8, 64, 64, 8, (1 << 20,), (257,), 4),     # per-GPU shard of cfgD (B=64 over 8 GPUs)
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def algorithmic_bytes(batch, cin, cout, groups, spatial, kernel, out_spatial):
+    """4*(input + weight + bias + output elements): SURVEY.md section 8d."""
+    n_in = batch * cin
+    n_out = batch * cout
+    for s in spatial:
+        n_in *= s
+    for s in out_spatial:
+        n_out *= s
+    n_w = cout * (cin // groups)
+    for k in kernel:
+        n_w *= k
+    return 4 * (n_in + n_w + cout + n_out), n_out
+
+
+def cpu_baseline(cfg, budget_s=15.0):
+    """The reference's CPU op sequence (oracle/fft_conv_oracle.py, torch CPU backend) timed on this
+    host's cores on a bounded sample: whole batches of the same workload until the budget is spent."""
+    from oracle.fft_conv_oracle import fft_conv_oracle_torch
+    ndim, batch, cin, cout, groups, spatial, kernel, dil = cfg
+    b = min(batch, 32)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(b, cin, *spatial, generator=g)
+    w = torch.randn(cout, cin // groups, *kernel, generator=g)
+    bias = torch.randn(cout, generator=g)
+    cores = torch.get_num_threads()
+    y = fft_conv_oracle_torch(x, w, bias, dilation=dil, groups=groups)    # warm-up
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while time.perf_counter() < t_end and len(times) < 50:
+        t0 = time.perf_counter()
+        fft_conv_oracle_torch(x, w, bias, dilation=dil, groups=groups)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": y.numel() / best / 1e9, "unit": "GSamples/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} passes of batch {b} of the same workload, best-of; torch {torch.__version__} CPU ops",
+            "ms_per_pass": best * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", default="cfgA", choices=sorted(CONFIGS))
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile", type=int, default=0, help="force the FFT tile length (0 = planner's choice)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.tile:
+        os.environ["FFTCONV_TILE"] = str(args.tile)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import fft_conv_pytorch_amd as fca
+    from fft_conv_pytorch_amd import _native
+
+    cfg = CONFIGS[args.config]
+    ndim, batch, cin, cout, groups, spatial, kernel, dil = cfg
+    Layer = {1: fca.FFTConv1d, 2: fca.FFTConv2d, 3: fca.FFTConv3d}[ndim]
+    torch.manual_seed(0)
+    layer = Layer(cin, cout, kernel, dilation=dil, groups=groups, bias=True)
+    with torch.no_grad():
+        layer.weight.normal_()
+        layer.bias.normal_()
+    layer = layer.to(dev)
+    if world > 1:   # the path's only exchange: weights from rank 0 (RCCL broadcast over xGMI)
+        dist.broadcast(layer.weight.data, src=0)
+        dist.broadcast(layer.bias.data, src=0)
+
+    # distinct buffer sets, > 2x the Infinity Cache in total
+    in_bytes = 4 * batch * cin
+    for s in spatial:
+        in_bytes *= s
+    nbuf = max(2, min(16, int(2.2 * 256 * 2**20 / (2 * in_bytes)) + 1))
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    xs = [torch.randn(batch, cin, *spatial, device=dev, generator=gen) for _ in range(nbuf)]
+    with torch.no_grad():
+        y0 = layer(xs[0])
+    out_spatial = tuple(y0.shape[2:])
+    ys = [torch.empty_like(y0) for _ in range(nbuf)]
+    alg_bytes, n_out = algorithmic_bytes(batch, cin, cout, groups, spatial, kernel, out_spatial)
+
+    spectrum = layer.__dict__["_spectrum_cache"][1]
+    plan = spectrum.plan
+    bias_ptr = layer.bias.data_ptr()
+    stream = torch.cuda.current_stream(dev)
+
+    def step(i):
+        j = i % nbuf
+        plan.forward(xs[j].data_ptr(), spectrum.buf.data_ptr(), bias_ptr, ys[j].data_ptr(),
+                     spectrum.workspace.data_ptr() if spectrum.workspace is not None else None,
+                     torch.cuda.current_stream(dev).cuda_stream)
+
+    steps, warmup = args.steps, args.warmup
+    graph = None
+    if not args.no_graph:
+        # one rotation over the buffer sets per graph; steps is rounded to whole rotations
+        steps = max(nbuf, (steps // nbuf) * nbuf)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(stream)
+        with torch.cuda.stream(side):
+            for i in range(nbuf):
+                step(i)
+        stream.wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(nbuf):
+                step(i)
+
+    def run(n):
+        if graph is not None:
+            for _ in range(n // nbuf):
+                graph.replay()
+            for i in range(n % nbuf):
+                step(i)
+        else:
+            for i in range(n):
+                step(i)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    run(warmup)
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(steps)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed, dev_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    # light sanity check of the timed path's result (not a parity test: tests/ does that)
+    assert torch.isfinite(ys[0]).all() and torch.allclose(ys[0], y0, rtol=0, atol=0)
+
+    if rank == 0:
+        kernel_us = dev_ms * 1e3 / steps          # HIP-event time per launch on the launch stream
+        achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+        out = {
+            "metric": "GSamples/s (output elems/s), forward fft_conv",
+            "value": world * n_out * steps / elapsed / 1e9,
+            "unit": "GSamples/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed * 1e3 / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {ndim}D fft_conv B={batch}/GPU {cin}->{cout}ch groups={groups} "
+                                   f"spatial={list(spatial)} kernel={list(kernel)} dilation={dil} bias, fp32",
+                       "tile": plan.tile, "buffer_sets": nbuf, "hip_graph": graph is not None,
+                       "kernel_spectrum": "cached per weight version (FFTConv module)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": kernel_us},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+"""ctypes binding of libfftconv_amd.so (C ABI in include/fftconv_amd.h).
+
+There is deliberately no fallback: if the library is missing or a call fails,
+an exception is raised.  The product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, Optional, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libfftconv_amd.so"
+LIB_PATH = os.path.join(_HERE, LIB_NAME)
+
+FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
+PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
+ABI_VERSION = 1
+
+EXPORTS = (
+    "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
+    "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_transform_kernel", "fc_forward",
+)
+
+
+class FcDesc(ctypes.Structure):
+    """Mirror of ``struct fc_desc``."""
+    _fields_ = [
+        ("ndim", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("batch", ctypes.c_int64), ("in_channels", ctypes.c_int64), ("out_channels", ctypes.c_int64),
+        ("groups", ctypes.c_int64),
+        ("spatial", ctypes.c_int64 * 3), ("kernel", ctypes.c_int64 * 3), ("stride", ctypes.c_int64 * 3),
+        ("padding", ctypes.c_int64 * 3), ("dilation", ctypes.c_int64 * 3),
+        ("padding_mode", ctypes.c_int32), ("has_bias", ctypes.c_int32), ("tile_hint", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libfftconv_amd.so (built in-tree by ``__graft_entry__.build()`` / ``make``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C fft_conv_pytorch_amd/csrc`). There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        lib.fc_version.restype = i32
+        lib.fc_last_error.restype = ctypes.c_char_p
+        lib.fc_plan_create.argtypes = [ctypes.POINTER(FcDesc), ctypes.POINTER(vp)]
+        lib.fc_plan_create.restype = i32
+        lib.fc_plan_destroy.argtypes = [vp]
+        lib.fc_plan_destroy.restype = None
+        lib.fc_output_shape.argtypes = [vp, ctypes.POINTER(ctypes.c_int64 * 3)]
+        lib.fc_output_shape.restype = i32
+        lib.fc_kernel_spectrum_bytes.argtypes = [vp]
+        lib.fc_kernel_spectrum_bytes.restype = sz
+        lib.fc_workspace_bytes.argtypes = [vp]
+        lib.fc_workspace_bytes.restype = sz
+        lib.fc_plan_tile.argtypes = [vp]
+        lib.fc_plan_tile.restype = i32
+        lib.fc_transform_kernel.argtypes = [vp, vp, vp, vp, vp]
+        lib.fc_transform_kernel.restype = i32
+        lib.fc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        lib.fc_forward.restype = i32
+        if lib.fc_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_NAME}: ABI version {lib.fc_version()} != {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def _raise(lib, status: int):
+    msg = lib.fc_last_error().decode("utf-8", "replace")
+    if status == FC_ERR_INVALID:
+        raise ValueError(msg)
+    if status == FC_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(f"libfftconv_amd: {msg}")
+
+
+class Plan:
+    """Owns one ``fc_plan`` (immutable after creation; shareable between threads)."""
+
+    def __init__(self, key: Tuple):
+        (ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode, has_bias, tile_hint) = key
+        lib = load_library()
+        d = FcDesc()
+        d.ndim, d.dtype = ndim, 0
+        d.batch, d.in_channels, d.out_channels, d.groups = batch, cin, cout, groups
+        for i in range(3):
+            d.spatial[i] = spatial[i] if i < ndim else 1
+            d.kernel[i] = kernel[i] if i < ndim else 1
+            d.stride[i] = stride[i] if i < ndim else 1
+            d.padding[i] = padding[i] if i < ndim else 0
+            d.dilation[i] = dilation[i] if i < ndim else 1
+        d.padding_mode, d.has_bias, d.tile_hint = mode, int(has_bias), tile_hint
+        handle = ctypes.c_void_p()
+        st = lib.fc_plan_create(ctypes.byref(d), ctypes.byref(handle))
+        if st != FC_OK:
+            _raise(lib, st)
+        self._lib, self._h, self.key = lib, handle, key
+        out = (ctypes.c_int64 * 3)()
+        lib.fc_output_shape(handle, ctypes.byref(out))
+        self.out_spatial = tuple(int(out[i]) for i in range(ndim))
+        self.spectrum_bytes = int(lib.fc_kernel_spectrum_bytes(handle))
+        self.workspace_bytes = int(lib.fc_workspace_bytes(handle))
+        self.tile = int(lib.fc_plan_tile(handle))
+
+    def transform_kernel(self, weight_ptr: int, w_hat_ptr: int, workspace_ptr: Optional[int], stream: int):
+        st = self._lib.fc_transform_kernel(self._h, weight_ptr, w_hat_ptr, workspace_ptr, stream)
+        if st != FC_OK:
+            _raise(self._lib, st)
+
+    def forward(self, x_ptr: int, w_hat_ptr: int, bias_ptr: Optional[int], y_ptr: int,
+                workspace_ptr: Optional[int], stream: int):
+        st = self._lib.fc_forward(self._h, x_ptr, w_hat_ptr, bias_ptr, y_ptr, workspace_ptr, stream)
+        if st != FC_OK:
+            _raise(self._lib, st)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.fc_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_plans: Dict[Tuple, Plan] = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(device_index: int, key: Tuple) -> Plan:
+    """Plan cache keyed on (device, descriptor)."""
+    full = (device_index,) + key
+    plan = _plans.get(full)
+    if plan is None:
+        with _plans_lock:
+            plan = _plans.get(full)
+            if plan is None:
+                plan = Plan(key)
+                _plans[full] = plan
+    return plan
+
+
+def clear_plan_cache():
+    with _plans_lock:
+        _plans.clear()

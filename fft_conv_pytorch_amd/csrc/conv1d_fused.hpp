@@ -1,0 +1,298 @@
+// conv1d_fused.hpp -- the fused 1-D FFT-convolution kernel (overlap-save tiles).
+//
+// One workgroup = one unit (batch item b, channel group g, out-channel chunk oc,
+// tile t).  Everything between the input samples and the output samples stays on
+// chip (replaces functional.py:60-87 of the reference, rows a3..a10 of SURVEY 8a):
+//
+//   load    T input samples of CIB channels, padding mode folded into the index
+//           map, two real channels packed per complex sequence z = x0 + i*x1
+//   forward two-pass register/LDS FFT (fft_engine.hpp)
+//   mix     per bin pair (f, T-f): unpack the two real spectra of every pair,
+//           contract input channels against the pre-transformed kernel
+//           H[o][i][f] = conj(W_oi[f])/(2T)   (L2-resident, float4 = two i's),
+//           re-pack two output channels per complex sequence, in place in LDS
+//   inverse two-pass FFT, last pass writes the V = T-Kd+1 valid samples straight
+//           to HBM with stride decimation and bias.
+//
+// Channel counts are runtime; CIB (input channels per chunk, even) is a template
+// parameter so the contraction keeps its inputs in registers.  Chunks beyond the
+// first accumulate into a second LDS region.
+#pragma once
+#include "fft_engine.hpp"
+
+namespace fc {
+
+enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2, PAD_CIRCULAR = 3 };
+
+struct Conv1dArgs {
+  const float* x;        // (B, Cin, L)
+  const float4* wspec;   // [G][Cog_pad][Cig_pad/2][T/2] float4 = {H(o,2ip)[f], H(o,2ip+1)[f]}
+  const float* bias;     // (Cout) or null
+  float* y;              // (B, Cout, Lout)
+  const float2* twA;     // [P][N2]
+  const float2* twB;     // [S][P]
+  int B, Cin, Cout, G, Cig, Cog;
+  int Cig_pad, Cog_pad;  // padded to CIB / COB multiples (spectrum layout)
+  int cob;               // out channels per chunk (even)
+  int n_ochunks;         // Cog_pad / cob
+  int L, pad, pad_mode;
+  int Kd, V, ntiles, Lfull, Lout, stride;
+  int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
+};
+
+// Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with
+// wave-uniform (a, b) per side, chosen from the padding mode (reflect: -pos /
+// 2(L-1)-pos, replicate: 0 / L-1, circular: pos+L / pos-L); constant mode and
+// positions beyond the padded extent read as zero.
+struct PadMap {
+  int lo_a, lo_b, hi_a, hi_b, live;   // live = 0 for constant mode
+};
+__device__ __forceinline__ PadMap make_padmap(int mode, int L) {
+  PadMap m;
+  m.live = (mode != PAD_CONSTANT);
+  m.lo_a = (mode == PAD_REFLECT) ? -1 : (mode == PAD_CIRCULAR ? 1 : 0);
+  m.hi_a = m.lo_a;
+  m.lo_b = (mode == PAD_CIRCULAR) ? L : 0;
+  m.hi_b = (mode == PAD_REFLECT) ? 2 * (L - 1) : (mode == PAD_REPLICATE ? L - 1 : (mode == PAD_CIRCULAR ? -L : 0));
+  return m;
+}
+__device__ __forceinline__ float load_padded(const float* __restrict__ row, int pos, int L, int pad, const PadMap& m,
+                                             bool chan_ok) {
+  const bool inside = (unsigned)pos < (unsigned)L;
+  const int qm = (pos < 0) ? m.lo_a * pos + m.lo_b : m.hi_a * pos + m.hi_b;
+  int q = inside ? pos : qm;
+  q = min(max(q, 0), L - 1);
+  const bool ok = chan_ok && (inside || (m.live && pos >= -pad && pos < L + pad));
+  const float v = row[ok ? q : 0];
+  return ok ? v : 0.0f;
+}
+
+template <int P, int S, int CIB, int NT>
+__global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int NPI = CIB / 2;
+  constexpr int SEQ_PER_IT = NT / G::TS;  // sequences processed concurrently
+  static_assert(NPI <= SEQ_PER_IT, "one sequence per thread per pass");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+
+  // ---- unit decode: id = ((b*ntiles + tile)*n_ochunks + oc)*G + g  (g fastest: a
+  // group's spectrum stays on one XCD's L2 when G is a multiple of 8)
+  int id = blockIdx.x;
+  const int g = id % a.G; id /= a.G;
+  const int oc = id % a.n_ochunks; id /= a.n_ochunks;
+  const int tile = id % a.ntiles;
+  const int b = id / a.ntiles;
+
+  const int tid = threadIdx.x;
+  const int seq0 = tid / G::TS;
+  const int tseq = tid % G::TS;
+  const int npo = a.cob / 2;
+  float2* zin = lds;
+  float2* vout = a.accumulate ? lds + NPI * G::LSEQ : lds;
+
+  const int n_ichunks = a.Cig_pad / CIB;
+  const int tile_pos = tile * a.V - a.pad;     // signal coordinate of tile sample 0
+  const bool interior = (tile_pos >= 0) && (tile_pos + T <= a.L);
+  const PadMap pm = make_padmap(a.pad_mode, a.L);
+  // buffer descriptors from uniform values only (no waterfall loops)
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const BufRsrc xg = make_rsrc(a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L, (unsigned)a.Cig * (unsigned)a.L * 4u);
+  const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
+  const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
+
+  for (int ic = 0; ic < n_ichunks; ++ic) {
+    // ------------------------------------------------ forward pass A (global -> regs -> LDS)
+    if (seq0 < NPI) {
+      const int sq = seq0;
+      const int ci0 = ic * CIB + 2 * sq;         // channel within the group
+      float re[P], im[P];
+      const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;
+      const float* r0 = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig + ci0) * a.L;
+      const float* r1 = r0 + a.L;
+      if (interior && has1) {
+        const unsigned v0 = ((unsigned)ci0 * (unsigned)a.L + (unsigned)(tile_pos + tseq)) * 4u;
+        const unsigned v1 = v0 + (unsigned)a.L * 4u;
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          re[n1] = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+          im[n1] = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+        }
+      } else {
+        // border tile / odd channel count: a rolled loop stages this thread's own
+        // column in LDS (no long-lived masks, no register-array indexing), then the
+        // column is read back -- same thread, same addresses, so no barrier.
+        float2* col = zin + sq * G::LSEQ + tseq;
+#pragma unroll 1
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int pos = tile_pos + G::N2 * n1 + tseq;
+          col[n1 * G::RS] = make_float2(load_padded(r0, pos, a.L, a.pad, pm, has0),
+                                        load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1));
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const float2 v = col[n1 * G::RS];
+          re[n1] = v.x; im[n1] = v.y;
+        }
+      }
+      fft_regs<P, -1>(re, im);
+      passA_twiddle_store<G, -1>(re, im, zin + sq * G::LSEQ, tseq, twA);
+    }
+    __syncthreads();
+    // ------------------------------------------------ forward pass B (LDS -> regs -> LDS natural)
+    {
+      // every row is read before anyone writes: the two layouts alias
+      float re[P], im[P];
+      if (seq0 < NPI) passB_load<G>(re, im, zin + seq0 * G::LSEQ, tseq);
+      __syncthreads();
+      if (seq0 < NPI) {
+        const int j = passB_compute<G, -1>(re, im, tseq, twB);
+        const int k1 = tseq >> G::LGS;
+        float2* dst = zin + seq0 * G::LSEQ + G::nat(k1 + P * P * j);   // nat() pad is constant per j block
+#pragma unroll
+        for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+      }
+    }
+    __syncthreads();
+    // ------------------------------------------------ mix: channel contraction per bin pair
+    {
+      // byte offsets inside the group's spectrum: uniform part in SGPRs, lane part = f*16
+      const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;   // bytes between output channels
+      const unsigned wbase = (unsigned)(oc * a.cob) * ostride + (unsigned)(ic * NPI) * (T / 2) * 16u;
+#pragma unroll 1
+      for (int f = tid; f < T / 2; f += NT) {
+        float xr[CIB], xi[CIB];
+        if (f != 0) {
+          const int fm = T - f;
+#pragma unroll
+          for (int p = 0; p < NPI; ++p) {
+            const float2 zf = zin[p * G::LSEQ + G::nat(f)];
+            const float2 zg = zin[p * G::LSEQ + G::nat(fm)];
+            xr[2 * p] = zf.x + zg.x;      xi[2 * p] = zf.y - zg.y;        // 2*X_even[f]
+            xr[2 * p + 1] = zf.y + zg.y;  xi[2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
+          }
+#pragma unroll 1
+          for (int q = 0; q < npo; ++q) {
+            float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
+            const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) {
+              const float4 ha = buf_load_f32x4(wg, (unsigned)f * 16u, sa + p * (T / 2) * 16);
+              const float4 hb = buf_load_f32x4(wg, (unsigned)f * 16u, sb + p * (T / 2) * 16);
+              yar = fmaf(xr[2 * p], ha.x, yar); yar = fmaf(-xi[2 * p], ha.y, yar);
+              yai = fmaf(xr[2 * p], ha.y, yai); yai = fmaf(xi[2 * p], ha.x, yai);
+              yar = fmaf(xr[2 * p + 1], ha.z, yar); yar = fmaf(-xi[2 * p + 1], ha.w, yar);
+              yai = fmaf(xr[2 * p + 1], ha.w, yai); yai = fmaf(xi[2 * p + 1], ha.z, yai);
+              ybr = fmaf(xr[2 * p], hb.x, ybr); ybr = fmaf(-xi[2 * p], hb.y, ybr);
+              ybi = fmaf(xr[2 * p], hb.y, ybi); ybi = fmaf(xi[2 * p], hb.x, ybi);
+              ybr = fmaf(xr[2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[2 * p + 1], hb.w, ybr);
+              ybi = fmaf(xr[2 * p + 1], hb.w, ybi); ybi = fmaf(xi[2 * p + 1], hb.z, ybi);
+            }
+            // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
+            float2 vf = make_float2(yar - ybi, yai + ybr);
+            float2 vg = make_float2(yar + ybi, ybr - yai);
+            float2* pf = vout + q * G::LSEQ + G::nat(f);
+            float2* pg = vout + q * G::LSEQ + G::nat(fm);
+            if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
+            *pf = vf; *pg = vg;
+          }
+        } else {
+          // bins 0 and T/2 are self-paired; both spectra are real there.
+          // wspec[.][f=0] holds {Re H[0], Re H[T/2]} per input channel.
+#pragma unroll
+          for (int p = 0; p < NPI; ++p) {
+            const float2 z0 = zin[p * G::LSEQ + G::nat(0)];
+            const float2 zh = zin[p * G::LSEQ + G::nat(T / 2)];
+            xr[2 * p] = 2.f * z0.x; xr[2 * p + 1] = 2.f * z0.y;   // bin 0
+            xi[2 * p] = 2.f * zh.x; xi[2 * p + 1] = 2.f * zh.y;   // bin T/2
+          }
+#pragma unroll 1
+          for (int q = 0; q < npo; ++q) {
+            float a0 = 0.f, b0 = 0.f, ah = 0.f, bh = 0.f;
+            const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) {
+              const float4 ha = buf_load_f32x4(wg, 0u, sa + p * (T / 2) * 16);
+              const float4 hb = buf_load_f32x4(wg, 0u, sb + p * (T / 2) * 16);
+              a0 = fmaf(xr[2 * p], ha.x, a0); a0 = fmaf(xr[2 * p + 1], ha.z, a0);
+              ah = fmaf(xi[2 * p], ha.y, ah); ah = fmaf(xi[2 * p + 1], ha.w, ah);
+              b0 = fmaf(xr[2 * p], hb.x, b0); b0 = fmaf(xr[2 * p + 1], hb.z, b0);
+              bh = fmaf(xi[2 * p], hb.y, bh); bh = fmaf(xi[2 * p + 1], hb.w, bh);
+            }
+            float2 v0 = make_float2(a0, b0), vh = make_float2(ah, bh);
+            float2* p0 = vout + q * G::LSEQ + G::nat(0);
+            float2* ph = vout + q * G::LSEQ + G::nat(T / 2);
+            if (ic != 0) { const float2 o0 = *p0, oh = *ph; v0.x += o0.x; v0.y += o0.y; vh.x += oh.x; vh.y += oh.y; }
+            *p0 = v0; *ph = vh;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // -------------------------------------------------- inverse pass A' (LDS natural -> regs -> LDS rows)
+  {
+    float re[P], im[P];
+    const bool act = seq0 < npo;
+    if (act) {
+      const float2* src = vout + seq0 * G::LSEQ;
+#pragma unroll
+      for (int i1 = 0; i1 < P; ++i1) {
+        const float2 v = src[G::nat(G::N2 * i1 + tseq)];
+        re[i1] = v.x; im[i1] = v.y;
+      }
+    }
+    __syncthreads();
+    if (act) {
+      fft_regs<P, +1>(re, im);
+      passA_twiddle_store<G, +1>(re, im, vout + seq0 * G::LSEQ, tseq, twA);
+    }
+  }
+  __syncthreads();
+  // -------------------------------------------------- inverse pass B' (LDS -> regs -> HBM)
+  if (seq0 < npo) {
+    const int sq = seq0;
+    float re[P], im[P];
+    passB_load<G>(re, im, vout + sq * G::LSEQ, tseq);
+    const int j = passB_compute<G, +1>(re, im, tseq, twB);
+    const int o1 = tseq >> G::LGS;
+    const int co0 = oc * a.cob + 2 * sq;           // out channel within the group
+    const bool has0 = co0 < a.Cog, has1 = co0 + 1 < a.Cog;
+    const int cg0 = g * a.Cog + co0;
+    const float bias0 = (a.bias && has0) ? a.bias[cg0] : 0.f;
+    const float bias1 = (a.bias && has1) ? a.bias[cg0 + 1] : 0.f;
+    const int t0 = tile * a.V;
+    const int limit = min(a.V, a.Lfull - t0);      // valid samples of this tile
+    const int nbase = o1 + P * P * j;
+    if (a.stride == 1) {
+      float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + t0 + nbase;
+      float* y1 = y0 + a.Lout;
+      if (has1) {
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) { y0[P * k] = re[k] + bias0; y1[P * k] = im[k] + bias1; }
+      } else if (has0) {
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) y0[P * k] = re[k] + bias0;
+      }
+    } else {
+      float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout;
+      float* y1 = y0 + a.Lout;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int n = nbase + P * k;
+        const int t = t0 + n;
+        const int idx = t / a.stride;
+        if (n < limit && idx * a.stride == t) {
+          if (has0) y0[idx] = re[k] + bias0;
+          if (has1) y1[idx] = im[k] + bias1;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace fc

@@ -1,0 +1,282 @@
+// fc_api.cpp -- C ABI of libfftconv_amd.so (see include/fftconv_amd.h).
+//
+// Host-side planning for the forward FFT convolution: hyper-parameter checks,
+// tile choice, twiddle tables, launch geometry.  The arithmetic of
+// /root/reference/fft_conv_pytorch/functional.py:44-47,66,76-82 that runs on the
+// host lives here; everything else is in the HIP kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fc_internal.h"
+#include "fftconv_amd.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define FC_HIP(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(FC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+const fc::TileImpl* const* all_tiles(int* n) {
+  static const fc::TileImpl* tiles[] = {fc::get_tile_P8_S1(),  fc::get_tile_P16_S1(), fc::get_tile_P16_S2(),
+                                        fc::get_tile_P32_S1(), fc::get_tile_P32_S2(), fc::get_tile_P32_S4()};
+  *n = (int)(sizeof tiles / sizeof tiles[0]);
+  return tiles;
+}
+
+const fc::TileImpl* find_tile(int T) {
+  int n;
+  auto t = all_tiles(&n);
+  for (int i = 0; i < n; ++i)
+    if (t[i]->T == T) return t[i];
+  return nullptr;
+}
+
+// Device twiddle tables, shared by every plan of the same tile geometry and device.
+struct Twiddles {
+  float2* twA = nullptr;  // [P][N2]  exp(-2 pi i n2 k1 / T)
+  float2* twB = nullptr;  // [S][P]   exp(-2 pi i r k / N2)
+};
+std::mutex g_tw_mutex;
+std::map<std::pair<int, int>, Twiddles> g_tw;  // (device, T)
+
+int get_twiddles(const fc::TileImpl* t, Twiddles* out) {
+  int dev = 0;
+  FC_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  auto key = std::make_pair(dev, t->T);
+  auto it = g_tw.find(key);
+  if (it != g_tw.end()) { *out = it->second; return FC_OK; }
+  const int P = t->P, S = t->S, N2 = P * S, T = t->T;
+  std::vector<float2> a((size_t)P * N2), b((size_t)S * P);
+  const double tau = 6.283185307179586476925286766559;
+  for (int k1 = 0; k1 < P; ++k1)
+    for (int n2 = 0; n2 < N2; ++n2) {
+      const double ang = -tau * (double)((long long)k1 * n2 % T) / (double)T;
+      a[(size_t)k1 * N2 + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+  for (int r = 0; r < S; ++r)
+    for (int k = 0; k < P; ++k) {
+      const double ang = -tau * (double)(r * k) / (double)N2;
+      b[(size_t)r * P + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+    }
+  Twiddles tw;
+  FC_HIP(hipMalloc(&tw.twA, a.size() * sizeof(float2)));
+  FC_HIP(hipMalloc(&tw.twB, b.size() * sizeof(float2)));
+  FC_HIP(hipMemcpy(tw.twA, a.data(), a.size() * sizeof(float2), hipMemcpyHostToDevice));
+  FC_HIP(hipMemcpy(tw.twB, b.data(), b.size() * sizeof(float2), hipMemcpyHostToDevice));
+  g_tw[key] = tw;
+  *out = tw;
+  return FC_OK;
+}
+
+int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+struct fc_plan {
+  fc_desc d;
+  int nd;
+  int64_t out_sp[3];
+  int64_t kd[3];      // dilated kernel extent per axis
+  // channel blocking
+  int Cig, Cog, CB, cob, Cig_pad, Cog_pad, n_ochunks, accumulate;
+  // last-axis (fused) tiling
+  const fc::TileImpl* tile;
+  Twiddles tw;
+  int V, ntiles, Lfull;
+  size_t lds_conv, lds_spec;
+  size_t spectrum_bytes, workspace_bytes;
+};
+
+extern "C" {
+
+int fc_version(void) { return FC_ABI_VERSION; }
+
+const char* fc_last_error(void) { return g_err.c_str(); }
+
+static int plan_1d(fc_plan* p) {
+  const fc_desc& d = p->d;
+  const int64_t L = d.spatial[0], pad = d.padding[0], Kd = p->kd[0];
+  const int64_t Lfull = L + 2 * pad - Kd + 1;
+  p->Lfull = (int)Lfull;
+  if (L * (int64_t)std::max(p->Cig, 1) * 4 >= (int64_t)1 << 32)
+    return fail(FC_ERR_UNSUPPORTED, "1-D signal too long for 32-bit buffer offsets (Cin/groups * L * 4 must be < 4 GiB)");
+
+  const int NPI = p->CB / 2;
+  const size_t lds_cap = 160 * 1024;
+  const fc::TileImpl* best = nullptr;
+  double best_cost = 0;
+  int ntl;
+  auto tiles = all_tiles(&ntl);
+  for (int i = 0; i < ntl; ++i) {
+    const fc::TileImpl* t = tiles[i];
+    if (d.tile_hint && t->T != d.tile_hint) continue;
+    if (t->T < Kd) continue;
+    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(float2);
+    if (lds > lds_cap) continue;
+    if (t->NT / (t->P * t->S) < NPI) continue;
+    const int64_t V = t->T - Kd + 1;
+    const int64_t nt = (Lfull + V - 1) / V;
+    // work model: FFT passes + channel mix per tile; the largest tile runs one
+    // workgroup per CU (LDS), which costs latency hiding
+    double cost = (double)nt * t->T * (2.0 * std::log2((double)t->T) + 4.0 + p->CB);
+    if (lds > 80 * 1024) cost *= 1.25;
+    if (!best || cost < best_cost) { best = t; best_cost = cost; }
+  }
+  if (!best) {
+    if (d.tile_hint) return fail(FC_ERR_INVALID, "tile_hint %d is not usable for this problem", d.tile_hint);
+    return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld exceeds the largest FFT tile (4096)", (long long)Kd);
+  }
+  p->tile = best;
+  p->V = (int)(best->T - Kd + 1);
+  p->ntiles = (int)((Lfull + p->V - 1) / p->V);
+  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * NPI * best->lseq * sizeof(float2);
+  p->lds_spec = (size_t)(best->NT / (best->P * best->S)) * best->lseq * sizeof(float2);
+  const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(float4);
+  if (per_group >= ((size_t)1 << 32))
+    return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
+  p->spectrum_bytes = per_group * (size_t)d.groups;
+  p->workspace_bytes = 0;
+  return get_twiddles(best, &p->tw);
+}
+
+int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
+  if (!desc || !out_plan) return fail(FC_ERR_INVALID, "null argument");
+  *out_plan = nullptr;
+  const fc_desc& d = *desc;
+  if (d.ndim < 1 || d.ndim > 3) return fail(FC_ERR_INVALID, "ndim must be 1, 2 or 3 (got %d)", d.ndim);
+  if (d.dtype != FC_F32) return fail(FC_ERR_UNSUPPORTED, "only float32 is supported");
+  if (d.batch < 1 || d.in_channels < 1 || d.out_channels < 1 || d.groups < 1)
+    return fail(FC_ERR_INVALID, "batch, channels and groups must be positive");
+  if (d.in_channels % d.groups || d.out_channels % d.groups)
+    return fail(FC_ERR_INVALID, "in_channels (%lld) and out_channels (%lld) must be divisible by groups (%lld)",
+                (long long)d.in_channels, (long long)d.out_channels, (long long)d.groups);
+  if (d.padding_mode < 0 || d.padding_mode > 3) return fail(FC_ERR_INVALID, "unknown padding_mode %d", d.padding_mode);
+
+  fc_plan* p = new fc_plan();
+  std::memset(p, 0, sizeof *p);
+  p->d = d;
+  p->nd = d.ndim;
+  for (int i = 0; i < d.ndim; ++i) {
+    if (d.spatial[i] < 1 || d.kernel[i] < 1 || d.stride[i] < 1 || d.dilation[i] < 1 || d.padding[i] < 0) {
+      delete p;
+      return fail(FC_ERR_INVALID, "axis %d: spatial/kernel/stride/dilation must be >= 1 and padding >= 0", i);
+    }
+    p->kd[i] = (d.kernel[i] - 1) * d.dilation[i] + 1;
+    const int64_t span = d.spatial[i] + 2 * d.padding[i] - p->kd[i];
+    if (span < 0) {
+      delete p;
+      return fail(FC_ERR_INVALID, "axis %d: dilated kernel extent %lld is larger than the padded input %lld", i,
+                  (long long)p->kd[i], (long long)(d.spatial[i] + 2 * d.padding[i]));
+    }
+    p->out_sp[i] = span / d.stride[i] + 1;
+    if (d.padding_mode == FC_PAD_REFLECT && d.padding[i] >= d.spatial[i]) {
+      delete p;
+      return fail(FC_ERR_INVALID, "axis %d: reflect padding (%lld) must be smaller than the input size (%lld)", i,
+                  (long long)d.padding[i], (long long)d.spatial[i]);
+    }
+    if (d.padding_mode == FC_PAD_CIRCULAR && d.padding[i] > d.spatial[i]) {
+      delete p;
+      return fail(FC_ERR_INVALID, "axis %d: circular padding (%lld) must not exceed the input size (%lld)", i,
+                  (long long)d.padding[i], (long long)d.spatial[i]);
+    }
+  }
+  p->Cig = (int)(d.in_channels / d.groups);
+  p->Cog = (int)(d.out_channels / d.groups);
+  const int cmax = std::max(p->Cig, p->Cog);
+  p->CB = cmax <= 2 ? 2 : (cmax <= 4 ? 4 : 8);
+  p->Cig_pad = (int)round_up(p->Cig, p->CB);
+  p->cob = std::min(p->CB, (int)round_up(p->Cog, 2));
+  p->Cog_pad = (int)round_up(p->Cog, p->cob);
+  p->n_ochunks = p->Cog_pad / p->cob;
+  p->accumulate = p->Cig_pad > p->CB;
+
+  int rc;
+  if (d.ndim == 1) rc = plan_1d(p);
+  else rc = fail(FC_ERR_UNSUPPORTED, "%d-D convolution is not built yet", d.ndim);
+  if (rc != FC_OK) { delete p; return rc; }
+  *out_plan = p;
+  return FC_OK;
+}
+
+void fc_plan_destroy(fc_plan* plan) { delete plan; }
+
+int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]) {
+  if (!plan || !out_spatial) return fail(FC_ERR_INVALID, "null argument");
+  for (int i = 0; i < 3; ++i) out_spatial[i] = i < plan->nd ? plan->out_sp[i] : 1;
+  return FC_OK;
+}
+
+size_t fc_kernel_spectrum_bytes(const fc_plan* plan) { return plan ? plan->spectrum_bytes : 0; }
+size_t fc_workspace_bytes(const fc_plan* plan) { return plan ? plan->workspace_bytes : 0; }
+int fc_plan_tile(const fc_plan* plan) { return plan && plan->tile ? plan->tile->T : 0; }
+
+int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, void* workspace, void* hip_stream) {
+  if (!plan || !weight || !w_hat) return fail(FC_ERR_INVALID, "null argument");
+  (void)workspace;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const fc_plan& p = *plan;
+  if (p.nd == 1) {
+    fc::Spec1dArgs a;
+    a.w = weight;
+    a.wspec = (float4*)w_hat;
+    a.twA = p.tw.twA;
+    a.twB = p.tw.twB;
+    a.G = (int)p.d.groups; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
+    a.K = (int)p.d.kernel[0]; a.dil = (int)p.d.dilation[0];
+    a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
+    const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
+    const int grid = (a.nseq + per_wg - 1) / per_wg;
+    FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
+    return FC_OK;
+  }
+  return fail(FC_ERR_UNSUPPORTED, "%d-D not built yet", p.nd);
+}
+
+int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y, void* workspace,
+               void* hip_stream) {
+  if (!plan || !x || !w_hat || !y) return fail(FC_ERR_INVALID, "null argument");
+  (void)workspace;
+  hipStream_t st = (hipStream_t)hip_stream;
+  const fc_plan& p = *plan;
+  if (p.d.has_bias && !bias) return fail(FC_ERR_INVALID, "plan was created with has_bias=1 but bias is NULL");
+  if (p.nd == 1) {
+    fc::Conv1dArgs a;
+    a.x = x; a.wspec = (const float4*)w_hat; a.bias = p.d.has_bias ? bias : nullptr; a.y = y;
+    a.twA = p.tw.twA; a.twB = p.tw.twB;
+    a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
+    a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
+    a.L = (int)p.d.spatial[0]; a.pad = (int)p.d.padding[0]; a.pad_mode = p.d.padding_mode;
+    a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
+    a.stride = (int)p.d.stride[0]; a.accumulate = p.accumulate;
+    const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;
+    if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
+    FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
+    return FC_OK;
+  }
+  return fail(FC_ERR_UNSUPPORTED, "%d-D not built yet", p.nd);
+}
+
+}  // extern "C"

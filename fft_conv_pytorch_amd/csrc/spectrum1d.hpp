@@ -1,0 +1,89 @@
+// spectrum1d.hpp -- kernel (weight) transform for the fused 1-D path.
+//
+// Replaces rows a2 + a6 of SURVEY 8a (functional.py:49-57 and :71): dilation is a
+// scatter of the taps to positions k*d, the zero padding to the tile length T is
+// implicit, two real kernels (o, 2ip), (o, 2ip+1) ride one complex FFT, and the
+// result is stored conjugated, scaled by 1/(2T) (inverse-FFT norm and the 1/2 of
+// the spectrum unpacking) in the layout the fused kernel's mix step streams:
+//   wspec[((g*Cog_pad + o)*(Cig_pad/2) + ip)*(T/2) + f] = {H(o,2ip)[f], H(o,2ip+1)[f]}
+// with H[.][0] = {Re H[0], Re H[T/2]} (both bins are real).  Phantom channels
+// (padding up to the chunk size) get zeros.
+#pragma once
+#include "fft_engine.hpp"
+
+namespace fc {
+
+struct Spec1dArgs {
+  const float* w;      // (Cout, Cig, K)
+  float4* wspec;
+  const float2* twA;
+  const float2* twB;
+  int G, Cig, Cog, Cig_pad, Cog_pad, K, dil, nseq;
+};
+
+template <int P, int S, int NT>
+__global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int SEQ_PER_WG = NT / G::TS;
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const int tid = threadIdx.x;
+  const int sl = tid / G::TS, tseq = tid % G::TS;
+  const int seq = blockIdx.x * SEQ_PER_WG + sl;
+  const bool act = seq < a.nseq;
+  float2* z = lds + sl * G::LSEQ;
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+
+  const int npi = a.Cig_pad / 2;
+  const int ip = act ? seq % npi : 0;
+  const int o = act ? (seq / npi) % a.Cog_pad : 0;
+  const int g = act ? seq / (npi * a.Cog_pad) : 0;
+  {
+    float re[P], im[P];
+    const bool has0 = act && o < a.Cog && 2 * ip < a.Cig;
+    const bool has1 = act && o < a.Cog && 2 * ip + 1 < a.Cig;
+    const float* w0 = a.w + ((size_t)(g * a.Cog + o) * a.Cig + 2 * ip) * a.K;
+    const float* w1 = w0 + a.K;
+#pragma unroll
+    for (int n1 = 0; n1 < P; ++n1) {
+      const int n = G::N2 * n1 + tseq;
+      const int tap = n / a.dil;
+      const bool hit = (tap * a.dil == n) && tap < a.K;
+      re[n1] = (hit && has0) ? w0[tap] : 0.f;
+      im[n1] = (hit && has1) ? w1[tap] : 0.f;
+    }
+    fft_regs<P, -1>(re, im);
+    passA_twiddle_store<G, -1>(re, im, z, tseq, twA);
+  }
+  __syncthreads();
+  {
+    float re[P], im[P];
+    passB_load<G>(re, im, z, tseq);
+    __syncthreads();
+    const int j = passB_compute<G, -1>(re, im, tseq, twB);
+    const int k1 = tseq >> G::LGS;
+    float2* dst = z + G::nat(k1 + P * P * j);
+#pragma unroll
+    for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+  }
+  __syncthreads();
+  if (!act) return;
+  const float sc = 0.5f / (float)T;
+  float4* out = a.wspec + (size_t)seq * (T / 2);
+  for (int f = tseq; f < T / 2; f += G::TS) {
+    float4 h;
+    if (f == 0) {
+      const float2 z0 = z[G::nat(0)], zh = z[G::nat(T / 2)];
+      h = make_float4(z0.x * sc, zh.x * sc, z0.y * sc, zh.y * sc);
+    } else {
+      const float2 zf = z[G::nat(f)], zg = z[G::nat(T - f)];
+      // W_a = (Zf + conj(Zg))/2, W_b = (Zf - conj(Zg))/(2i); H = conj(W)/(2T)
+      const float h2 = 0.5f * sc;
+      h = make_float4((zf.x + zg.x) * h2, -(zf.y - zg.y) * h2, (zf.y + zg.y) * h2, -(zg.x - zf.x) * h2);
+    }
+    out[f] = h;
+  }
+}
+
+}  // namespace fc

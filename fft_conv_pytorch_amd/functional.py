@@ -1,0 +1,139 @@
+"""``fft_conv`` for MI355X: same call signature as the reference, HIP kernels underneath.
+
+Mirrors /root/reference/fft_conv_pytorch/functional.py (fft_conv :19-89,
+complex_matmul :11-16, to_ntuple re-export :8).  The Python layer only
+normalises arguments, checks shapes, allocates the output and hands raw device
+pointers + the current HIP stream to libfftconv_amd.so.  There is no CPU path
+and no torch.fft / rocFFT / hipFFT call anywhere in this package.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, Optional, Union
+
+import torch
+from torch import Tensor
+
+from . import _native
+from .utils import to_ntuple
+
+__all__ = ["fft_conv", "fft_conv_transpose", "complex_matmul", "to_ntuple", "transform_kernel", "KernelSpectrum"]
+
+
+def _require_gpu_f32(name: str, t: Tensor):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"fft_conv_pytorch_amd: `{name}` is on {t.device}; this implementation runs on ROCm devices only "
+            f"(no CPU fallback). Move the tensor to 'cuda'.")
+    if t.dtype != torch.float32:
+        raise TypeError(f"fft_conv_pytorch_amd: `{name}` has dtype {t.dtype}; only torch.float32 is supported")
+
+
+class KernelSpectrum:
+    """A weight tensor transformed for one plan (rows a2 + a6); reusable while the weight is unchanged."""
+
+    __slots__ = ("plan", "buf", "workspace")
+
+    def __init__(self, plan, buf, workspace):
+        self.plan, self.buf, self.workspace = plan, buf, workspace
+
+
+def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=0):
+    n = signal.ndim - 2
+    if n < 1 or n > 3:
+        raise ValueError(f"fft_conv expects (batch, channels, *spatial) with 1-3 spatial dims, got shape {tuple(signal.shape)}")
+    if kernel.ndim != signal.ndim:
+        raise ValueError(f"kernel has {kernel.ndim} dims but signal has {signal.ndim}")
+    padding_ = to_ntuple(padding, n=n)
+    stride_ = to_ntuple(stride, n=n)
+    dilation_ = to_ntuple(dilation, n=n)
+    if padding_mode not in _native.PAD_MODES:
+        raise ValueError(f"unknown padding_mode {padding_mode!r}; expected one of constant/zeros/reflect/replicate/circular")
+    if not isinstance(groups, int) or groups < 1:
+        raise ValueError(f"groups must be a positive int, got {groups!r}")
+    cin, cout = int(signal.shape[1]), int(kernel.shape[0])
+    if cin % groups or cout % groups or int(kernel.shape[1]) * groups != cin:
+        raise ValueError(
+            f"channel mismatch: signal has {cin} channels, kernel is {tuple(kernel.shape)} with groups={groups} "
+            f"(need kernel.shape[1] * groups == in_channels and out_channels % groups == 0)")
+    if bias is not None and tuple(bias.shape) != (cout,):
+        raise ValueError(f"bias must have shape ({cout},), got {tuple(bias.shape)}")
+    key = (n, int(signal.shape[0]), cin, cout, groups,
+           tuple(int(s) for s in signal.shape[2:]), tuple(int(k) for k in kernel.shape[2:]),
+           tuple(int(s) for s in stride_), tuple(int(p) for p in padding_), tuple(int(d) for d in dilation_),
+           _native.PAD_MODES[padding_mode], bias is not None, int(tile_hint))
+    # host-side validation is complete; only now touch the device library
+    _require_gpu_f32("signal", signal)
+    _require_gpu_f32("kernel", kernel)
+    if bias is not None:
+        _require_gpu_f32("bias", bias)
+    return _native.get_plan(signal.device.index or 0, key)
+
+
+def transform_kernel(plan, kernel: Tensor) -> KernelSpectrum:
+    """Kernel transform (dilate, zero-pad, FFT, conjugate) on the device; rows a2 + a6."""
+    _require_gpu_f32("kernel", kernel)
+    kernel = kernel.detach().contiguous()
+    with torch.cuda.device(kernel.device):
+        buf = torch.empty(max(plan.spectrum_bytes, 16) // 4, dtype=torch.float32, device=kernel.device)
+        ws = torch.empty(plan.workspace_bytes // 4, dtype=torch.float32, device=kernel.device) if plan.workspace_bytes else None
+        stream = torch.cuda.current_stream(kernel.device).cuda_stream
+        plan.transform_kernel(kernel.data_ptr(), buf.data_ptr(), ws.data_ptr() if ws is not None else None, stream)
+    return KernelSpectrum(plan, buf, ws)
+
+
+def _forward_native(signal: Tensor, spectrum: KernelSpectrum, bias: Optional[Tensor]) -> Tensor:
+    plan = spectrum.plan
+    signal = signal.detach().contiguous()
+    bias_c = bias.detach().contiguous() if bias is not None else None
+    with torch.cuda.device(signal.device):
+        out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=torch.float32, device=signal.device)
+        stream = torch.cuda.current_stream(signal.device).cuda_stream
+        plan.forward(signal.data_ptr(), spectrum.buf.data_ptr(), bias_c.data_ptr() if bias_c is not None else None,
+                     out.data_ptr(), spectrum.workspace.data_ptr() if spectrum.workspace is not None else None, stream)
+    return out
+
+
+def fft_conv(
+    signal: Tensor,
+    kernel: Tensor,
+    bias: Tensor = None,
+    stride: Union[int, Iterable[int]] = 1,
+    padding: Union[int, Iterable[int]] = 0,
+    dilation: Union[int, Iterable[int]] = 1,
+    groups: int = 1,
+    padding_mode: str = "constant",
+) -> Tensor:
+    """N-d (1/2/3) cross-correlation through FFTs, equal to ``torch.nn.functional.conv{N}d``.
+
+    Args and result as in the reference (functional.py:19-42): ``signal`` is
+    (B, Cin, *spatial), ``kernel`` is (Cout, Cin/groups, *k), ``bias`` is (Cout,)
+    or None; ``stride``/``padding``/``dilation`` are ints or per-axis iterables;
+    ``padding_mode`` is one of constant | reflect | replicate | circular.
+    The result is a fresh contiguous (B, Cout, *out) float32 tensor on the
+    input's device.  Unlike the reference, a kernel larger than the padded
+    input raises ``ValueError`` (torch's behaviour) instead of returning a
+    wrongly shaped tensor.
+    """
+    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode,
+                     tile_hint=int(os.environ.get("FFTCONV_TILE", "0")))
+    spectrum = transform_kernel(plan, kernel)     # the reference also re-transforms per call (functional.py:71)
+    return _forward_native(signal, spectrum, bias)
+
+
+def fft_conv_transpose(*args, **kwargs):
+    raise NotImplementedError(
+        "fft_conv_transpose is outside this round's hot-path scope (SURVEY section 8f, row N2); "
+        "the forward fft_conv / FFTConv{1,2,3}d path is implemented.")
+
+
+def complex_matmul(a: Tensor, b: Tensor, groups: int = 1) -> Tensor:
+    """Grouped per-bin channel contraction ``einsum('bgi...,goi...->bgo...')`` (functional.py:11-16).
+
+    In this implementation the contraction is fused into the convolution kernels
+    (the "mix" step), so ``fft_conv`` never calls this function; it is kept for
+    API compatibility and evaluates the same contraction on the tensors' device.
+    """
+    a_g = a.unflatten(1, [groups, a.size(1) // groups])
+    b_g = b.unflatten(0, [groups, b.size(0) // groups])
+    return torch.einsum("bgi...,goi...->bgo...", a_g, b_g).flatten(1, 2)

@@ -1,0 +1,96 @@
+/* fftconv_amd.h -- C ABI of libfftconv_amd.so (MI355X / gfx950 FFT convolution).
+ *
+ * The reference (klae01/fft-conv-pytorch) has no FFI: its boundary is the Python
+ * signature fft_conv(signal, kernel, bias, stride, padding, dilation, groups,
+ * padding_mode) at fft_conv_pytorch/functional.py:19-28.  This ABI is what a
+ * native backend for that function binds to; each entry point cites the piece
+ * of the reference it replaces.  Plain pointers and sizes only -- no torch
+ * types.  All device buffers are owned by the caller; the library owns only the
+ * plan (device twiddle tables + launch geometry).  Every launch is asynchronous
+ * on the caller's stream; no entry point on the hot path allocates or
+ * synchronises.  Status: 0 = OK, non-zero = error, text via fc_last_error().
+ */
+#ifndef FFTCONV_AMD_H
+#define FFTCONV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FC_ABI_VERSION 1
+
+enum fc_status {
+  FC_OK = 0,
+  FC_ERR_INVALID = 1,      /* bad argument / shape (ValueError on the Python side) */
+  FC_ERR_UNSUPPORTED = 2,  /* valid but outside what this build handles */
+  FC_ERR_HIP = 3           /* a HIP runtime call failed */
+};
+
+enum fc_pad_mode { FC_PAD_CONSTANT = 0, FC_PAD_REFLECT = 1, FC_PAD_REPLICATE = 2, FC_PAD_CIRCULAR = 3 };
+enum fc_dtype { FC_F32 = 0 };
+
+/* Problem descriptor: the arguments of functional.py:19-28 after to_ntuple
+ * (utils.py:4-20) has been applied on the host side.  Axis order is the tensor
+ * order: spatial[0] is the slowest spatial axis. */
+typedef struct fc_desc {
+  int32_t ndim;          /* 1, 2 or 3 spatial axes */
+  int32_t dtype;         /* fc_dtype */
+  int64_t batch;
+  int64_t in_channels;
+  int64_t out_channels;
+  int64_t groups;
+  int64_t spatial[3];    /* input extent per axis (unpadded) */
+  int64_t kernel[3];     /* kernel taps per axis */
+  int64_t stride[3];
+  int64_t padding[3];
+  int64_t dilation[3];
+  int32_t padding_mode;  /* fc_pad_mode; "zeros" of nn.Conv == constant (nn.py:12) */
+  int32_t has_bias;
+  int32_t tile_hint;     /* 0 = auto; otherwise force the 1-D FFT tile length */
+  int32_t reserved;
+} fc_desc;
+
+typedef struct fc_plan fc_plan;
+
+/* ABI version of the loaded library (FC_ABI_VERSION). */
+int fc_version(void);
+
+/* Thread-local text of the last error returned on this thread. */
+const char* fc_last_error(void);
+
+/* Validate the descriptor, choose tiles and build device twiddle tables.
+ * Host-side arithmetic of functional.py:44-47,66 (a1, a4). May allocate. */
+int fc_plan_create(const fc_desc* desc, fc_plan** out_plan);
+void fc_plan_destroy(fc_plan* plan);
+
+/* Output extent per spatial axis: floor((S + 2p - d(k-1) - 1)/stride) + 1,
+ * the slice arithmetic of functional.py:76-82 (a9). */
+int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]);
+
+/* Bytes the caller must provide for the transformed kernel / the scratch area. */
+size_t fc_kernel_spectrum_bytes(const fc_plan* plan);
+size_t fc_workspace_bytes(const fc_plan* plan);
+
+/* FFT tile length chosen for the last (fused) axis, for reporting. */
+int fc_plan_tile(const fc_plan* plan);
+
+/* Kernel transform: dilation scatter + zero pad + real FFT + conjugate
+ * (functional.py:49-57 and :71; rows a2, a6).  weight is (Cout, Cin/groups, *k)
+ * contiguous fp32 on the device; w_hat receives fc_kernel_spectrum_bytes(). */
+int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, void* workspace,
+                        void* hip_stream);
+
+/* Forward convolution (functional.py:60-87; rows a3, a5, a7-a10): padding,
+ * forward real FFT, per-bin grouped channel contraction, inverse FFT, valid
+ * window, stride, bias -- x is (B, Cin, *spatial), y is (B, Cout, *out) fp32
+ * contiguous on the device.  bias may be NULL. */
+int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
+               void* workspace, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFTCONV_AMD_H */

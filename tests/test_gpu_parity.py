@@ -1,0 +1,187 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, the committed golden
+vectors from the real reference, and torch's direct convolution.  Tolerance: 1e-4 relative
+(max|y - y_ref| / max|y_ref|), the bar BASELINE.json's north_star states for fp32."""
+import itertools
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import fft_conv_oracle as orc
+from tests import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4
+DEV = "cuda:0"
+
+
+def _hip(x, w, b, **kw):
+    from fft_conv_pytorch_amd.functional import fft_conv
+    t = lambda a: None if a is None else torch.as_tensor(a).to(DEV)
+    y = fft_conv(t(x), t(w), bias=t(b), **kw)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def test_native_library_is_loaded():
+    from fft_conv_pytorch_amd import _native
+    lib = _native.load_library()
+    assert lib.fc_version() == _native.ABI_VERSION
+    with open("/proc/self/maps") as f:
+        assert _native.LIB_NAME in f.read()
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3])
+def test_golden_g1_reference_grid(ndim):
+    worst, n_cases = 0.0, 0
+    for n, x, w, b, kw, y_ref in gu.g1_cases():
+        if x.ndim - 2 != ndim:
+            continue
+        worst = max(worst, gu.check_against(_hip(x, w, b, **kw), y_ref, REL_TOL))
+        n_cases += 1
+    assert n_cases > 0
+    print(f"G1 ndim={ndim}: {n_cases} cases, worst rel err {worst:.2e}")
+
+
+def test_golden_g2_extended():
+    for n, x, w, b, kw, gold in gu.g2_cases():
+        err = gu.check_against(_hip(x, w, b, **kw), gold, REL_TOL)
+        print(f"G2 case {n}: rel err {err:.2e}")
+
+
+@pytest.mark.parametrize("name", ["cfg0", "cfgA", "cfgB", "cfgC", "cfgD_b1"])
+def test_golden_g3_baseline_configs(name):
+    x, w, b, kw, gold = gu.g3_case(name)
+    err = gu.check_against(_hip(x, w, b, **kw), gold, REL_TOL)
+    print(f"G3 {name}: rel err {err:.2e}")
+
+
+def _gcd3(a, b, c):
+    return math.gcd(a, math.gcd(b, c))
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3])
+def test_full_reference_grid_against_torch_direct(ndim):
+    """The reference's whole 1,152-case grid (tests/test_functional.py:11-20), seeded, against
+    torch's direct convolution on the CPU -- the same ground truth the reference uses -- with the
+    reference's own absolute tolerance (benchmark_utils.py:53-57)."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(1234 + ndim)
+    conv = getattr(F, f"conv{ndim}d")
+    grid = itertools.product([2, 3], [2, 3], [1, 2, 3], [2, 3], [0, 1], [1, 2], [1, 2], [7, 8])
+    count = 0
+    for cin, cout, groups, k, pad, stride, dil, size in grid:
+        g = _gcd3(cin, cout, groups)
+        x = torch.randn(2, cin, *([size] * ndim), generator=gen)
+        w = torch.randn(cout, cin // g, *([k] * ndim), generator=gen)
+        b = torch.randn(cout, generator=gen)
+        kw = dict(stride=stride, padding=pad, dilation=dil, groups=g)
+        y = fft_conv(x.to(DEV), w.to(DEV), bias=b.to(DEV), **kw).cpu()
+        y_ref = conv(x, w, bias=b, **kw)
+        assert y.shape == y_ref.shape
+        err = (y - y_ref).abs()
+        assert err.max().item() < 1e-4 and err.mean().item() < 5e-5, (cin, cout, g, k, pad, stride, dil, size)
+        count += 1
+    assert count == 384
+
+
+@pytest.mark.parametrize("mode", ["constant", "reflect", "replicate", "circular"])
+@pytest.mark.parametrize("shape", [((300,), (17,), (8,)), ((2500,), (65,), (40,)), ((40, 37), (5, 4), (3, 2)),
+                                   ((9, 12, 11), (3, 2, 3), (2, 1, 2))])
+def test_padding_modes_against_oracle(mode, shape):
+    spatial, ksz, pad = shape
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((2, 4) + spatial, dtype=np.float32)
+    w = rng.standard_normal((6, 2) + ksz, dtype=np.float32)
+    b = rng.standard_normal(6, dtype=np.float32)
+    kw = dict(padding=pad, groups=2, padding_mode=mode)
+    y_ref = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+    assert orc.rel_err(_hip(x, w, b, **kw), y_ref) < REL_TOL
+
+
+@pytest.mark.parametrize("cin,cout,groups", [(1, 1, 1), (1, 5, 1), (5, 1, 1), (7, 9, 1), (16, 24, 1), (12, 20, 4),
+                                             (64, 64, 8), (20, 10, 5), (9, 9, 9)])
+def test_channel_blocking_1d(cin, cout, groups):
+    """Odd channel counts (zero phantom channels), several input chunks (LDS accumulate path) and
+    several output chunks; multi-channel groups are never exercised by the reference's own tests."""
+    rng = np.random.default_rng(cin * 100 + cout)
+    x = rng.standard_normal((2, cin, 3000), dtype=np.float32)
+    w = rng.standard_normal((cout, cin // groups, 33), dtype=np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    kw = dict(padding=16, groups=groups)
+    y_ref = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+    assert orc.rel_err(_hip(x, w, b, **kw), y_ref) < REL_TOL
+
+
+@pytest.mark.parametrize("tile", [64, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("stride,dilation", [(1, 1), (3, 2)])
+def test_every_tile_geometry_1d(tile, stride, dilation, monkeypatch):
+    """Force each FFT tile length (all (P, S) register/lane-split geometries) on a multi-tile row."""
+    monkeypatch.setenv("FFTCONV_TILE", str(tile))
+    k = 9
+    rng = np.random.default_rng(tile)
+    length = 3 * tile + 123
+    x = rng.standard_normal((2, 3, length), dtype=np.float32)
+    w = rng.standard_normal((5, 3, k), dtype=np.float32)
+    b = rng.standard_normal(5, dtype=np.float32)
+    kw = dict(stride=stride, dilation=dilation, padding=4)
+    y_ref = orc.fft_conv_oracle_torch(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b), **kw).numpy()
+    assert orc.rel_err(_hip(x, w, b, **kw), y_ref) < REL_TOL
+
+
+def test_edge_cases_1d():
+    rng = np.random.default_rng(3)
+    # kernel as long as the (padded) input -> single output sample
+    x = rng.standard_normal((1, 2, 9), dtype=np.float32)
+    w = rng.standard_normal((2, 2, 9), dtype=np.float32)
+    y_ref = orc.direct_conv_float64(x, w)
+    assert orc.rel_err(_hip(x, w, None), y_ref) < REL_TOL
+    # 1-tap kernel, no bias
+    w1 = rng.standard_normal((3, 2, 1), dtype=np.float32)
+    assert orc.rel_err(_hip(x, w1, None), orc.direct_conv_float64(x, w1)) < REL_TOL
+    # non-contiguous input views
+    xb = rng.standard_normal((2, 4, 200), dtype=np.float32)
+    from fft_conv_pytorch_amd.functional import fft_conv
+    xt = torch.from_numpy(xb).to(DEV)[:, ::2, ::2]
+    wt = torch.from_numpy(rng.standard_normal((3, 2, 5), dtype=np.float32)).to(DEV)
+    y = fft_conv(xt, wt).cpu().numpy()
+    assert orc.rel_err(y, orc.direct_conv_float64(xb[:, ::2, ::2], wt.cpu().numpy())) < REL_TOL
+    # kernel larger than padded input: torch raises, the reference silently mis-shapes; we raise
+    with pytest.raises(ValueError):
+        fft_conv(torch.zeros(1, 1, 4, device=DEV), torch.zeros(1, 1, 6, device=DEV))
+
+
+def test_linearity_and_shift_at_full_size():
+    """Size-independent properties at the metric configuration (cfgA): linearity in the signal and
+    translation equivariance -- no oracle needed at this size."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x1 = torch.randn(32, 8, 32768, device=DEV, generator=g)
+    x2 = torch.randn(32, 8, 32768, device=DEV, generator=g)
+    w = torch.randn(8, 8, 512, device=DEV, generator=g)
+    y1, y2 = fft_conv(x1, w), fft_conv(x2, w)
+    y12 = fft_conv(2.0 * x1 - 3.0 * x2, w)
+    scale = y12.abs().max().item()
+    assert (y12 - (2.0 * y1 - 3.0 * y2)).abs().max().item() / scale < REL_TOL
+    ys = fft_conv(torch.roll(x1, 100, dims=-1), w)
+    assert (ys[..., 100:] - y1[..., :-100]).abs().max().item() / scale < REL_TOL
+
+
+def test_module_matches_functional_and_tracks_weight_updates():
+    from fft_conv_pytorch_amd import FFTConv1d
+    torch.manual_seed(0)
+    layer = FFTConv1d(4, 6, 31, padding=15, padding_mode="reflect").to(DEV)
+    x = torch.randn(3, 4, 2000, device=DEV)
+    ref = lambda: F.conv1d(F.pad(x, (15, 15), mode="reflect"), layer.weight, layer.bias)
+    y = layer(x)
+    assert (y - ref()).abs().max().item() / ref().abs().max().item() < REL_TOL
+    with torch.no_grad():
+        layer.weight.mul_(0.5)          # bumps weight._version -> spectrum cache must refresh
+    y2 = layer(x)
+    assert (y2 - ref()).abs().max().item() / ref().abs().max().item() < REL_TOL
+    sd = layer.state_dict()
+    assert set(sd) == {"weight", "bias"}
+    with pytest.raises(AssertionError):
+        layer(x[0])                     # unbatched input is rejected like the reference (nn.py:11)

@@ -66,7 +66,9 @@ def cpu_baseline(cfg, budget_s=15.0):
     x = torch.randn(b, cin, *spatial, generator=g)
     w = torch.randn(cout, cin // groups, *kernel, generator=g)
     bias = torch.randn(cout, generator=g)
-    cores = torch.get_num_threads()
+    # the GPU box shares its host: use this process's CPU share, not every core of the machine
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("FFTCONV_CPU_THREADS", "16"))))
+    torch.set_num_threads(cores)
     y = fft_conv_oracle_torch(x, w, bias, dilation=dil, groups=groups)    # warm-up
     times = []
     t_end = time.perf_counter() + budget_s

@@ -12,7 +12,7 @@ from typing import Dict, Optional, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfftconv_amd.so"
-LIB_PATH = os.path.join(_HERE, LIB_NAME)
+LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, LIB_NAME)   # env: A/B builds while tuning
 
 FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
 PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
@@ -21,6 +21,7 @@ ABI_VERSION = 1
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
     "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_transform_kernel", "fc_forward",
+    "fc_debug_set_stamps", "fc_debug_grid",
 )
 
 
@@ -77,6 +78,10 @@ def load_library() -> ctypes.CDLL:
         lib.fc_transform_kernel.restype = i32
         lib.fc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         lib.fc_forward.restype = i32
+        lib.fc_debug_set_stamps.argtypes = [vp, vp]
+        lib.fc_debug_set_stamps.restype = i32
+        lib.fc_debug_grid.argtypes = [vp]
+        lib.fc_debug_grid.restype = ctypes.c_longlong
         if lib.fc_version() != ABI_VERSION:
             raise ImportError(f"{LIB_NAME}: ABI version {lib.fc_version()} != {ABI_VERSION}")
         _lib = lib
@@ -130,6 +135,12 @@ class Plan:
         st = self._lib.fc_forward(self._h, x_ptr, w_hat_ptr, bias_ptr, y_ptr, workspace_ptr, stream)
         if st != FC_OK:
             _raise(self._lib, st)
+
+    def debug_set_stamps(self, ptr: Optional[int]):
+        self._lib.fc_debug_set_stamps(self._h, ptr)
+
+    def debug_grid(self) -> int:
+        return int(self._lib.fc_debug_grid(self._h))
 
     def __del__(self):
         try:

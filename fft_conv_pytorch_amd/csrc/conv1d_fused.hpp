@@ -38,6 +38,7 @@ struct Conv1dArgs {
   int L, pad, pad_mode;
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
+  unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
 };
 
 // Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with
@@ -65,6 +66,11 @@ __device__ __forceinline__ float load_padded(const float* __restrict__ row, int 
   const bool ok = chan_ok && (inside || (m.live && pos >= -pad && pos < L + pad));
   const float v = row[ok ? q : 0];
   return ok ? v : 0.0f;
+}
+
+// Profiling hook: lane 0 of each workgroup records the 100 MHz wall clock at phase boundaries.
+__device__ __forceinline__ void stamp(unsigned long long* buf, int slot) {
+  if (buf != nullptr && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int P, int S, int CIB, int NT>
@@ -102,6 +108,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
 
+  stamp(a.stamps, 0);
   for (int ic = 0; ic < n_ichunks; ++ic) {
     // ------------------------------------------------ forward pass A (global -> regs -> LDS)
     if (seq0 < NPI) {
@@ -136,10 +143,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           re[n1] = v.x; im[n1] = v.y;
         }
       }
+      if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.stamps, 1); }
       fft_regs<P, -1>(re, im);
       passA_twiddle_store<G, -1>(re, im, zin + sq * G::LSEQ, tseq, twA);
     }
+    stamp(a.stamps, 2);
     __syncthreads();
+    stamp(a.stamps, 3);
     // ------------------------------------------------ forward pass B (LDS -> regs -> LDS natural)
     {
       // every row is read before anyone writes: the two layouts alias
@@ -154,82 +164,100 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
       }
     }
+    stamp(a.stamps, 4);
     __syncthreads();
+    stamp(a.stamps, 5);
     // ------------------------------------------------ mix: channel contraction per bin pair
     {
       // byte offsets inside the group's spectrum: uniform part in SGPRs, lane part = f*16
       const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;   // bytes between output channels
       const unsigned wbase = (unsigned)(oc * a.cob) * ostride + (unsigned)(ic * NPI) * (T / 2) * 16u;
+      constexpr int FB = (T / 2 >= 2 * NT) ? 2 : 1;   // bin pairs per thread per iteration
+      if (tid == 0) {
+        // bins 0 and T/2 are self-paired and both spectra are real there;
+        // wspec[.][f=0] holds {Re H[0], Re H[T/2]} per input channel.
+        float x0[CIB], xh[CIB];
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          const float2 z0 = zin[p * G::LSEQ + G::nat(0)];
+          const float2 zh = zin[p * G::LSEQ + G::nat(T / 2)];
+          x0[2 * p] = 2.f * z0.x; x0[2 * p + 1] = 2.f * z0.y;
+          xh[2 * p] = 2.f * zh.x; xh[2 * p + 1] = 2.f * zh.y;
+        }
 #pragma unroll 1
-      for (int f = tid; f < T / 2; f += NT) {
-        float xr[CIB], xi[CIB];
-        if (f != 0) {
-          const int fm = T - f;
+        for (int q = 0; q < npo; ++q) {
+          float a0 = 0.f, b0 = 0.f, ah = 0.f, bh = 0.f;
+          const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#pragma unroll
+          for (int p = 0; p < NPI; ++p) {
+            const float4 ha = buf_load_f32x4(wg, 0u, sa + p * (T / 2) * 16);
+            const float4 hb = buf_load_f32x4(wg, 0u, sb + p * (T / 2) * 16);
+            a0 = fmaf(x0[2 * p], ha.x, a0); a0 = fmaf(x0[2 * p + 1], ha.z, a0);
+            ah = fmaf(xh[2 * p], ha.y, ah); ah = fmaf(xh[2 * p + 1], ha.w, ah);
+            b0 = fmaf(x0[2 * p], hb.x, b0); b0 = fmaf(x0[2 * p + 1], hb.z, b0);
+            bh = fmaf(xh[2 * p], hb.y, bh); bh = fmaf(xh[2 * p + 1], hb.w, bh);
+          }
+          float2 v0 = make_float2(a0, b0), vh = make_float2(ah, bh);
+          float2* p0 = vout + q * G::LSEQ + G::nat(0);
+          float2* ph = vout + q * G::LSEQ + G::nat(T / 2);
+          if (ic != 0) { const float2 o0 = *p0, oh = *ph; v0.x += o0.x; v0.y += o0.y; vh.x += oh.x; vh.y += oh.y; }
+          *p0 = v0; *ph = vh;
+        }
+      }
+#pragma unroll 1
+      for (int fb = tid; fb < T / 2; fb += NT * FB) {
+        float xr[FB][CIB], xi[FB][CIB];
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+          const int f = fb + u * NT;
+          const int fm = (T - f) & (T - 1);           // f = 0 (thread 0) is redone harmlessly and skipped below
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
             const float2 zf = zin[p * G::LSEQ + G::nat(f)];
             const float2 zg = zin[p * G::LSEQ + G::nat(fm)];
-            xr[2 * p] = zf.x + zg.x;      xi[2 * p] = zf.y - zg.y;        // 2*X_even[f]
-            xr[2 * p + 1] = zf.y + zg.y;  xi[2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
+            xr[u][2 * p] = zf.x + zg.x;      xi[u][2 * p] = zf.y - zg.y;        // 2*X_even[f]
+            xr[u][2 * p + 1] = zf.y + zg.y;  xi[u][2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
           }
-#pragma unroll 1
-          for (int q = 0; q < npo; ++q) {
-            float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NPI; ++q) {
+          if (q < npo) {
             const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
 #pragma unroll
-            for (int p = 0; p < NPI; ++p) {
-              const float4 ha = buf_load_f32x4(wg, (unsigned)f * 16u, sa + p * (T / 2) * 16);
-              const float4 hb = buf_load_f32x4(wg, (unsigned)f * 16u, sb + p * (T / 2) * 16);
-              yar = fmaf(xr[2 * p], ha.x, yar); yar = fmaf(-xi[2 * p], ha.y, yar);
-              yai = fmaf(xr[2 * p], ha.y, yai); yai = fmaf(xi[2 * p], ha.x, yai);
-              yar = fmaf(xr[2 * p + 1], ha.z, yar); yar = fmaf(-xi[2 * p + 1], ha.w, yar);
-              yai = fmaf(xr[2 * p + 1], ha.w, yai); yai = fmaf(xi[2 * p + 1], ha.z, yai);
-              ybr = fmaf(xr[2 * p], hb.x, ybr); ybr = fmaf(-xi[2 * p], hb.y, ybr);
-              ybi = fmaf(xr[2 * p], hb.y, ybi); ybi = fmaf(xi[2 * p], hb.x, ybi);
-              ybr = fmaf(xr[2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[2 * p + 1], hb.w, ybr);
-              ybi = fmaf(xr[2 * p + 1], hb.w, ybi); ybi = fmaf(xi[2 * p + 1], hb.z, ybi);
-            }
-            // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
-            float2 vf = make_float2(yar - ybi, yai + ybr);
-            float2 vg = make_float2(yar + ybi, ybr - yai);
-            float2* pf = vout + q * G::LSEQ + G::nat(f);
-            float2* pg = vout + q * G::LSEQ + G::nat(fm);
-            if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
-            *pf = vf; *pg = vg;
-          }
-        } else {
-          // bins 0 and T/2 are self-paired; both spectra are real there.
-          // wspec[.][f=0] holds {Re H[0], Re H[T/2]} per input channel.
+            for (int u = 0; u < FB; ++u) {
+              const int f = fb + u * NT;
+              float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
 #pragma unroll
-          for (int p = 0; p < NPI; ++p) {
-            const float2 z0 = zin[p * G::LSEQ + G::nat(0)];
-            const float2 zh = zin[p * G::LSEQ + G::nat(T / 2)];
-            xr[2 * p] = 2.f * z0.x; xr[2 * p + 1] = 2.f * z0.y;   // bin 0
-            xi[2 * p] = 2.f * zh.x; xi[2 * p + 1] = 2.f * zh.y;   // bin T/2
-          }
-#pragma unroll 1
-          for (int q = 0; q < npo; ++q) {
-            float a0 = 0.f, b0 = 0.f, ah = 0.f, bh = 0.f;
-            const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-#pragma unroll
-            for (int p = 0; p < NPI; ++p) {
-              const float4 ha = buf_load_f32x4(wg, 0u, sa + p * (T / 2) * 16);
-              const float4 hb = buf_load_f32x4(wg, 0u, sb + p * (T / 2) * 16);
-              a0 = fmaf(xr[2 * p], ha.x, a0); a0 = fmaf(xr[2 * p + 1], ha.z, a0);
-              ah = fmaf(xi[2 * p], ha.y, ah); ah = fmaf(xi[2 * p + 1], ha.w, ah);
-              b0 = fmaf(xr[2 * p], hb.x, b0); b0 = fmaf(xr[2 * p + 1], hb.z, b0);
-              bh = fmaf(xi[2 * p], hb.y, bh); bh = fmaf(xi[2 * p + 1], hb.w, bh);
+              for (int p = 0; p < NPI; ++p) {
+                const float4 ha = buf_load_f32x4(wg, (unsigned)f * 16u, sa + p * (T / 2) * 16);
+                const float4 hb = buf_load_f32x4(wg, (unsigned)f * 16u, sb + p * (T / 2) * 16);
+                yar = fmaf(xr[u][2 * p], ha.x, yar); yar = fmaf(-xi[u][2 * p], ha.y, yar);
+                yai = fmaf(xr[u][2 * p], ha.y, yai); yai = fmaf(xi[u][2 * p], ha.x, yai);
+                yar = fmaf(xr[u][2 * p + 1], ha.z, yar); yar = fmaf(-xi[u][2 * p + 1], ha.w, yar);
+                yai = fmaf(xr[u][2 * p + 1], ha.w, yai); yai = fmaf(xi[u][2 * p + 1], ha.z, yai);
+                ybr = fmaf(xr[u][2 * p], hb.x, ybr); ybr = fmaf(-xi[u][2 * p], hb.y, ybr);
+                ybi = fmaf(xr[u][2 * p], hb.y, ybi); ybi = fmaf(xi[u][2 * p], hb.x, ybi);
+                ybr = fmaf(xr[u][2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[u][2 * p + 1], hb.w, ybr);
+                ybi = fmaf(xr[u][2 * p + 1], hb.w, ybi); ybi = fmaf(xi[u][2 * p + 1], hb.z, ybi);
+              }
+              if (f != 0) {
+                const int fm = T - f;
+                // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
+                float2 vf = make_float2(yar - ybi, yai + ybr);
+                float2 vg = make_float2(yar + ybi, ybr - yai);
+                float2* pf = vout + q * G::LSEQ + G::nat(f);
+                float2* pg = vout + q * G::LSEQ + G::nat(fm);
+                if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
+                *pf = vf; *pg = vg;
+              }
             }
-            float2 v0 = make_float2(a0, b0), vh = make_float2(ah, bh);
-            float2* p0 = vout + q * G::LSEQ + G::nat(0);
-            float2* ph = vout + q * G::LSEQ + G::nat(T / 2);
-            if (ic != 0) { const float2 o0 = *p0, oh = *ph; v0.x += o0.x; v0.y += o0.y; vh.x += oh.x; vh.y += oh.y; }
-            *p0 = v0; *ph = vh;
           }
         }
       }
     }
+    stamp(a.stamps, 6);
     __syncthreads();
+    stamp(a.stamps, 7);
   }
 
   // -------------------------------------------------- inverse pass A' (LDS natural -> regs -> LDS rows)
@@ -250,7 +278,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       passA_twiddle_store<G, +1>(re, im, vout + seq0 * G::LSEQ, tseq, twA);
     }
   }
+  stamp(a.stamps, 8);
   __syncthreads();
+  stamp(a.stamps, 9);
   // -------------------------------------------------- inverse pass B' (LDS -> regs -> HBM)
   if (seq0 < npo) {
     const int sq = seq0;
@@ -292,6 +322,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         }
       }
     }
+    stamp(a.stamps, 10);
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.stamps, 11); }
   }
 }
 

@@ -108,6 +108,15 @@ struct fc_plan {
   int V, ntiles, Lfull;
   size_t lds_conv, lds_spec;
   size_t spectrum_bytes, workspace_bytes;
+  void* debug_stamps;   // profiling hook (fc_debug_set_stamps)
+  // ---- N-d (2-D / 3-D): axis 0 = fused (outermost), axis nd-1 = rows (x), middle axis only in 3-D
+  const fc::TileImpl* tx;     // rows (last axis), full-length FFT
+  const fc::TileImpl* tm;     // middle axis (3-D), full-length FFT
+  Twiddles twx, twm;
+  int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
+  int Fx;                     // Tx/2 + 1
+  int nd_cob, nd_Cog_pad;
+  size_t ws_a, ws_b;          // float2 counts of the two workspace regions
 };
 
 extern "C" {
@@ -160,6 +169,94 @@ static int plan_1d(fc_plan* p) {
   p->spectrum_bytes = per_group * (size_t)d.groups;
   p->workspace_bytes = 0;
   return get_twiddles(best, &p->tw);
+}
+
+
+static const fc::TileImpl* smallest_tile_at_least(int64_t n) {
+  int ntl;
+  auto tiles = all_tiles(&ntl);
+  const fc::TileImpl* best = nullptr;
+  for (int i = 0; i < ntl; ++i)
+    if (tiles[i]->T >= n && (!best || tiles[i]->T < best->T)) best = tiles[i];
+  return best;
+}
+
+static int plan_nd(fc_plan* p) {
+  const fc_desc& d = p->d;
+  const int nd = p->nd;
+  for (int i = 0; i < nd; ++i) {
+    p->Sp[i] = (int)(d.spatial[i] + 2 * d.padding[i]);
+    p->Lf[i] = (int)(p->Sp[i] - p->kd[i] + 1);
+  }
+  // full-length transforms on the rows axis and (3-D) the middle axis
+  p->tx = smallest_tile_at_least(p->Sp[nd - 1]);
+  if (!p->tx) return fail(FC_ERR_UNSUPPORTED, "padded extent %d of the last axis exceeds the largest FFT (4096)", p->Sp[nd - 1]);
+  p->Fx = p->tx->T / 2 + 1;
+  p->tm = nullptr;
+  if (nd == 3) {
+    p->tm = smallest_tile_at_least(p->Sp[1]);
+    if (!p->tm) return fail(FC_ERR_UNSUPPORTED, "padded extent %d of the middle axis exceeds the largest FFT (4096)", p->Sp[1]);
+  }
+  // channel blocking of the fused (complex) pass: one sequence per channel
+  p->nd_cob = std::min(p->CB, p->Cog);
+  p->nd_Cog_pad = (int)round_up(p->Cog, p->nd_cob);
+  // overlap-save tiles along the outermost axis
+  const int64_t Kd = p->kd[0], Lfull = p->Lf[0];
+  const size_t lds_cap = 160 * 1024;
+  const fc::TileImpl* best = nullptr;
+  double best_cost = 0;
+  int ntl;
+  auto tiles = all_tiles(&ntl);
+  for (int i = 0; i < ntl; ++i) {
+    const fc::TileImpl* t = tiles[i];
+    if (d.tile_hint && t->T != d.tile_hint) continue;
+    if (t->T < Kd || p->CB > t->fusedc_max_cib) continue;
+    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * p->CB * t->lseqp * sizeof(float2);
+    if (lds > lds_cap) continue;
+    const int64_t V = t->T - Kd + 1;
+    const int64_t nt = (Lfull + V - 1) / V;
+    double cost = (double)nt * t->T * (2.0 * std::log2((double)t->T) + 4.0 + 2.0 * p->CB);
+    if (lds > 80 * 1024) cost *= 1.25;
+    if (!best || cost < best_cost) { best = t; best_cost = cost; }
+  }
+  if (!best) {
+    if (d.tile_hint) return fail(FC_ERR_INVALID, "tile_hint %d is not usable for this problem", d.tile_hint);
+    return fail(FC_ERR_UNSUPPORTED, "no FFT tile fits the outermost axis (dilated kernel extent %lld, %d channels per chunk)",
+                (long long)Kd, p->CB);
+  }
+  p->tile = best;
+  p->V = (int)(best->T - Kd + 1);
+  p->ntiles = (int)((Lfull + p->V - 1) / p->V);
+  p->Lfull = (int)Lfull;
+  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * p->CB * best->lseqp * sizeof(float2);
+
+  const size_t B = (size_t)d.batch, Ci = (size_t)d.in_channels, Co = (size_t)d.out_channels;
+  const size_t Fx = (size_t)p->Fx;
+  size_t ncol, a_sig, b_sig, a_w, b_w;
+  if (nd == 2) {
+    ncol = Fx;
+    a_sig = B * Ci * Fx * p->Sp[0];                       // S1[(b,ci)][fx][yp]
+    b_sig = B * Co * Fx * (size_t)p->out_sp[0];           // O1[(b,co)][fx][y_out]
+    a_w = Co * p->Cig * Fx * (size_t)p->kd[0];            // S1w[(o,i)][fx][y<Kd]
+    b_w = 0;
+  } else {
+    const size_t Ty = (size_t)p->tm->T;
+    ncol = Fx * Ty;
+    a_sig = std::max(B * Ci * p->Sp[0] * Fx * p->Sp[1],            // S1[(b,ci)][zp][fx][yp]
+                     B * Co * Fx * Ty * (size_t)p->out_sp[0]);      // O2[(b,co)][fx][fy][z_out]
+    b_sig = std::max(B * Ci * Fx * Ty * p->Sp[0],                   // S2[(b,ci)][fx][fy][zp]
+                     B * Co * (size_t)p->out_sp[0] * Fx * (size_t)p->out_sp[1]);   // O1[(b,co)][z_out][fx][y_out]
+    a_w = Co * p->Cig * (size_t)p->kd[0] * Fx * (size_t)p->kd[1];
+    b_w = Co * p->Cig * Fx * Ty * (size_t)p->kd[0];
+  }
+  p->ws_a = std::max(a_sig, a_w);
+  p->ws_b = std::max(b_sig, b_w);
+  p->workspace_bytes = (p->ws_a + p->ws_b) * sizeof(float2);
+  p->spectrum_bytes = (size_t)d.groups * p->nd_Cog_pad * (p->Cig_pad / 2) * ncol * best->T * sizeof(float4);
+  int rc = get_twiddles(best, &p->tw);
+  if (rc == FC_OK) rc = get_twiddles(p->tx, &p->twx);
+  if (rc == FC_OK && p->tm) rc = get_twiddles(p->tm, &p->twm);
+  return rc;
 }
 
 int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
@@ -215,7 +312,7 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
 
   int rc;
   if (d.ndim == 1) rc = plan_1d(p);
-  else rc = fail(FC_ERR_UNSUPPORTED, "%d-D convolution is not built yet", d.ndim);
+  else rc = plan_nd(p);
   if (rc != FC_OK) { delete p; return rc; }
   *out_plan = p;
   return FC_OK;
@@ -232,6 +329,17 @@ int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]) {
 size_t fc_kernel_spectrum_bytes(const fc_plan* plan) { return plan ? plan->spectrum_bytes : 0; }
 size_t fc_workspace_bytes(const fc_plan* plan) { return plan ? plan->workspace_bytes : 0; }
 int fc_plan_tile(const fc_plan* plan) { return plan && plan->tile ? plan->tile->T : 0; }
+
+int fc_debug_set_stamps(fc_plan* plan, void* device_buffer) {
+  if (!plan) return fail(FC_ERR_INVALID, "null argument");
+  plan->debug_stamps = device_buffer;
+  return FC_OK;
+}
+
+long long fc_debug_grid(const fc_plan* plan) {
+  if (!plan || plan->nd != 1) return 0;
+  return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->d.groups;
+}
 
 int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, void* workspace, void* hip_stream) {
   if (!plan || !weight || !w_hat) return fail(FC_ERR_INVALID, "null argument");
@@ -252,7 +360,46 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
     return FC_OK;
   }
-  return fail(FC_ERR_UNSUPPORTED, "%d-D not built yet", p.nd);
+  // ---- 2-D / 3-D: the separable passes, fed from the dilated taps
+  if (p.workspace_bytes && !workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
+  float2* wsA = (float2*)workspace;
+  float2* wsB = wsA + p.ws_a;
+  const int nd = p.nd;
+  const int Co = (int)p.d.out_channels;
+  FC_HIP(hipMemsetAsync(w_hat, 0, p.spectrum_bytes, st));    // phantom channels stay zero
+  fc::RowsR2CArgs r{};
+  r.src = weight; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 1;
+  r.kx = (int)p.d.kernel[nd - 1]; r.dx = (int)p.d.dilation[nd - 1];
+  r.ky = (int)p.d.kernel[nd - 2]; r.dy = (int)p.d.dilation[nd - 2];
+  r.kz = nd == 3 ? (int)p.d.kernel[0] : 1; r.dz = nd == 3 ? (int)p.d.dilation[0] : 1;
+  r.NA = Co * p.Cig; r.NC = nd == 3 ? (int)p.kd[0] : 1; r.NY = (int)p.kd[nd - 2]; r.NYa = r.NY;
+  r.SZ = r.kz; r.SY = r.ky; r.SX = r.kx; r.Fx = p.Fx;
+  FC_HIP(p.tx->rows_r2c(r, st));
+  const float norm = 1.0f / ((float)p.tx->T * (float)p.tile->T * (nd == 3 ? (float)p.tm->T : 1.0f));
+  fc::C2CArgs c{};
+  c.Cig = p.Cig; c.Cog = p.Cog; c.Cig_pad = p.Cig_pad; c.Cog_pad = p.nd_Cog_pad; c.scale = norm;
+  c.NV = 0; c.stride = 1;
+  if (nd == 2) {
+    // S1w[(o,i)][fx][y<Kd] -> wspec[..][fx][fy]
+    c.src = wsA; c.dst = (float2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
+    c.NA = Co * p.Cig; c.NC = 1; c.NB = p.Fx; c.NLEN = (int)p.kd[0];
+    c.sa = (long long)p.Fx * r.NYa; c.sc = 0; c.sb = r.NYa; c.store_mode = 1;
+    FC_HIP(p.tile->c2c_fwd(c, st));
+  } else {
+    const int Ty = p.tm->T, Kz = (int)p.kd[0];
+    // S1w[(o,i)][z<Kdz][fx][y<Kdy] -> S2w[(o,i)][fx][fy][z<Kdz]
+    c.src = wsA; c.dst = wsB; c.twA = p.twm.twA; c.twB = p.twm.twB;
+    c.NA = Co * p.Cig; c.NC = p.Fx; c.NB = Kz; c.NLEN = (int)p.kd[1];
+    c.sa = (long long)Kz * p.Fx * r.NYa; c.sb = (long long)p.Fx * r.NYa; c.sc = r.NYa;
+    c.ta = (long long)p.Fx * Ty * Kz; c.tc = (long long)Ty * Kz; c.tf = Kz; c.store_mode = 0;
+    FC_HIP(p.tm->c2c_fwd(c, st));
+    // S2w[(o,i)][(fx,fy)][z<Kdz] -> wspec[..][(fx,fy)][fz]
+    c.src = wsB; c.dst = (float2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
+    c.NC = 1; c.NB = p.Fx * Ty; c.NLEN = Kz;
+    c.sa = (long long)p.Fx * Ty * Kz; c.sc = 0; c.sb = Kz; c.store_mode = 1;
+    FC_HIP(p.tile->c2c_fwd(c, st));
+  }
+  return FC_OK;
 }
 
 int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y, void* workspace,
@@ -271,12 +418,67 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.L = (int)p.d.spatial[0]; a.pad = (int)p.d.padding[0]; a.pad_mode = p.d.padding_mode;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = (int)p.d.stride[0]; a.accumulate = p.accumulate;
+    a.stamps = (unsigned long long*)p.debug_stamps;
     const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;
     if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
     FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
     return FC_OK;
   }
-  return fail(FC_ERR_UNSUPPORTED, "%d-D not built yet", p.nd);
+  // ---- 2-D / 3-D
+  if (p.workspace_bytes && !workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
+  float2* wsA = (float2*)workspace;
+  float2* wsB = wsA + p.ws_a;
+  const int nd = p.nd;
+  const int B = (int)p.d.batch, Ci = (int)p.d.in_channels, Co = (int)p.d.out_channels;
+  auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = (int)p.d.padding[ax]; m.mode = p.d.padding_mode; return m; };
+  fc::RowsR2CArgs r{};
+  r.src = x; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 0;
+  r.mx = amap(nd - 1); r.my = amap(nd - 2); r.mz = amap(0);
+  r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1;
+  r.NA = B * Ci; r.NC = nd == 3 ? p.Sp[0] : 1; r.NY = p.Sp[nd - 2]; r.NYa = r.NY;
+  r.SZ = nd == 3 ? (int)p.d.spatial[0] : 1; r.SY = (int)p.d.spatial[nd - 2]; r.SX = (int)p.d.spatial[nd - 1]; r.Fx = p.Fx;
+  FC_HIP(p.tx->rows_r2c(r, st));
+
+  fc::FusedCArgs f{};
+  f.wspec = (const float4*)w_hat; f.twA = p.tw.twA; f.twB = p.tw.twB;
+  f.B = B; f.Cin = Ci; f.Cout = Co; f.G = (int)p.d.groups; f.Cig = p.Cig; f.Cog = p.Cog;
+  f.Cig_pad = p.Cig_pad; f.Cog_pad = p.nd_Cog_pad; f.cob = p.nd_cob; f.n_ochunks = p.nd_Cog_pad / p.nd_cob;
+  f.Kd = (int)p.kd[0]; f.V = p.V; f.ntiles = p.ntiles; f.Lfull = p.Lfull; f.NVo = (int)p.out_sp[0];
+  f.stride = (int)p.d.stride[0]; f.accumulate = p.accumulate; f.NLEN = p.Sp[0];
+
+  fc::RowsC2RArgs o{};
+  o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;
+  o.NA = B * Co; o.Fx = p.Fx; o.Cout = Co;
+  o.NV = p.Lf[nd - 1]; o.stride = (int)p.d.stride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
+  o.NY = (int)p.out_sp[nd - 2]; o.NYa = o.NY;
+
+  if (nd == 2) {
+    f.src = wsA; f.dst = wsB; f.ncol = p.Fx;
+    FC_HIP(p.tile->fusedc(p.CB, f, st));
+    o.src = wsB; o.NC = 1;
+    FC_HIP(p.tx->rows_c2r(o, st));
+  } else {
+    const int Ty = p.tm->T, Szp = p.Sp[0], Syp = p.Sp[1], Lzo = (int)p.out_sp[0], Lyo = (int)p.out_sp[1];
+    fc::C2CArgs c{};
+    c.scale = 1.f; c.store_mode = 0; c.twA = p.twm.twA; c.twB = p.twm.twB;
+    // S1[(b,ci)][zp][fx][yp] -> S2[(b,ci)][fx][fy][zp]
+    c.src = wsA; c.dst = wsB; c.NA = B * Ci; c.NC = p.Fx; c.NB = Szp; c.NLEN = Syp;
+    c.sa = (long long)Szp * p.Fx * Syp; c.sb = (long long)p.Fx * Syp; c.sc = Syp;
+    c.ta = (long long)p.Fx * Ty * Szp; c.tc = (long long)Ty * Szp; c.tf = Szp;
+    c.NV = 0; c.stride = 1;
+    FC_HIP(p.tm->c2c_fwd(c, st));
+    f.src = wsB; f.dst = wsA; f.ncol = p.Fx * Ty;
+    FC_HIP(p.tile->fusedc(p.CB, f, st));
+    // O2[(b,co)][fx][fy][z_out] -> O1[(b,co)][z_out][fx][y_out]
+    c.src = wsA; c.dst = wsB; c.NA = B * Co; c.NC = p.Fx; c.NB = Lzo;
+    c.sa = (long long)p.Fx * Ty * Lzo; c.sc = (long long)Ty * Lzo; c.sb = Lzo;
+    c.ta = (long long)Lzo * p.Fx * Lyo; c.tb = (long long)p.Fx * Lyo; c.tc = Lyo;
+    c.NV = p.Lf[1]; c.stride = (int)p.d.stride[1];
+    FC_HIP(p.tm->c2c_inv(c, st));
+    o.src = wsB; o.NC = Lzo;
+    FC_HIP(p.tx->rows_c2r(o, st));
+  }
+  return FC_OK;
 }
 
 }  // extern "C"

@@ -2,15 +2,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv1d_fused.hpp"
+#include "nd_passes.hpp"
 #include "spectrum1d.hpp"
 
 namespace fc {
 
 struct TileImpl {
   int T, P, S, NT;
-  int lseq;     // complex LDS slots per sequence
+  int lseq;     // complex LDS slots per sequence (fused 1-D kernel)
+  int lseqp;    // sequence stride used by the N-d passes
+  int nseq_c;   // sequences per workgroup of the c2c passes (rows passes: 2*nseq_r rows)
+  int nseq_r;
   hipError_t (*conv1d)(int cib, const Conv1dArgs& a, int grid, size_t lds, hipStream_t st);
   hipError_t (*spec1d)(const Spec1dArgs& a, int grid, size_t lds, hipStream_t st);
+  hipError_t (*rows_r2c)(const RowsR2CArgs& a, hipStream_t st);
+  hipError_t (*c2c_fwd)(const C2CArgs& a, hipStream_t st);
+  hipError_t (*c2c_inv)(const C2CArgs& a, hipStream_t st);
+  hipError_t (*rows_c2r)(const RowsC2RArgs& a, hipStream_t st);
+  hipError_t (*fusedc)(int cib, const FusedCArgs& a, hipStream_t st);   // hipErrorInvalidValue if cib unsupported
+  int fusedc_max_cib;
 };
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();

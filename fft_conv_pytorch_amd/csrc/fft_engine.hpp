@@ -36,6 +36,20 @@ __host__ __device__ constexpr float cos64(int q) {
 }
 __host__ __device__ constexpr float sin64(int q) { return cos64(q - 16); }
 
+// cos(2*pi*q/128) for odd q = 1,3,..,31 (the 128th roots that are not 64th roots)
+__device__ constexpr float kCos128odd[16] = {
+    0.99879545620517241f, 0.98917650996478101f, 0.97003125319454397f, 0.94154406518302081f,
+    0.90398929312344334f, 0.85772861000027212f, 0.80320753148064494f, 0.74095112535495911f,
+    0.67155895484701833f, 0.59569930449243336f, 0.51410274419322166f, 0.42755509343028208f,
+    0.33688985339222005f, 0.24298017990326387f, 0.14673047445536175f, 0.04906767432741801f};
+__host__ __device__ constexpr float cos128(int q) {
+  q &= 127;
+  if (q > 64) q = 128 - q;
+  if ((q & 1) == 0) return cos64(q >> 1);
+  return (q > 32) ? -kCos128odd[(64 - q) >> 1] : kCos128odd[q >> 1];
+}
+__host__ __device__ constexpr float sin128(int q) { return cos128(q - 32); }
+
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 __host__ __device__ constexpr int bitrev(int v, int bits) {
   int r = 0;
@@ -163,11 +177,21 @@ __device__ __forceinline__ int passB_compute(float (&re)[G::P], float (&im)[G::P
     return 0;
   } else {
     const int r = tseq & (G::S - 1);
+    // lane twiddle w_N2^(r*k): compile-time roots of unity (N2 <= 128), chosen per lane
+    static_assert(G::N2 <= 128, "lane-split twiddles come from the 128th-root table");
+    (void)twB;
     if (r != 0) {
 #pragma unroll
       for (int k = 1; k < G::P; ++k) {
-        const float2 w = buf_load_f32x2(twB, (unsigned)(r * G::P * 8), k * 8);
-        const float c = w.x, s = (DIR > 0) ? -w.y : w.y;
+        constexpr int STEP = 128 / G::N2;
+        float c = cos128(STEP * k), s = -sin128(STEP * k);
+        if constexpr (G::S == 4) {
+          const float c2 = cos128(2 * STEP * k), s2 = -sin128(2 * STEP * k);
+          const float c3 = cos128(3 * STEP * k), s3 = -sin128(3 * STEP * k);
+          c = (r == 1) ? c : ((r == 2) ? c2 : c3);
+          s = (r == 1) ? s : ((r == 2) ? s2 : s3);
+        }
+        if (DIR > 0) s = -s;
         const float xr = re[k], xi = im[k];
         re[k] = fmaf(c, xr, -s * xi);
         im[k] = fmaf(c, xi, s * xr);

@@ -1,0 +1,465 @@
+// nd_passes.hpp -- separable passes for 2-D / 3-D FFT convolution.
+//
+// The N-d transform of functional.py:70-75 (rfftn / irfftn over the last n axes)
+// is done one axis at a time; every pass reads sequences that are contiguous in
+// memory and writes its result TRANSPOSED so that the next pass's axis is
+// contiguous again (128-byte segments either way):
+//
+//   rows_r2c   last axis, real -> half spectrum (two rows ride one complex FFT),
+//              padding of every axis folded into the load index maps (a3, a5)
+//   c2c_fwd    middle axis of a 3-D problem
+//   fusedc     outermost spatial axis: forward FFT, channel contraction against
+//              the transformed kernel, inverse FFT (overlap-save tiles) (a7)
+//   c2c_inv    middle axis back
+//   rows_c2r   last axis back, valid window + stride + bias (a8, a9, a10)
+//
+// The same passes, fed from the dilated, zero-padded kernel taps instead of the
+// signal, produce the kernel spectrum (a2, a6).
+#pragma once
+#include "conv1d_fused.hpp"
+
+namespace fc {
+
+// Index map of one padded axis: position p in [0, n_padded) -> source index or -1 (zero).
+struct AxisMap {
+  int size;       // unpadded extent
+  int pad;        // left padding
+  int mode;       // PadMode
+};
+__device__ __forceinline__ int axis_src(const AxisMap& m, int p) {   // p: padded coordinate
+  const int pos = p - m.pad;
+  if ((unsigned)pos < (unsigned)m.size) return pos;
+  if (pos < -m.pad || pos >= m.size + m.pad || m.mode == PAD_CONSTANT) return -1;
+  if (m.mode == PAD_REFLECT) return pos < 0 ? -pos : 2 * (m.size - 1) - pos;
+  if (m.mode == PAD_REPLICATE) return pos < 0 ? 0 : m.size - 1;
+  return pos < 0 ? pos + m.size : pos - m.size;
+}
+// Kernel taps: position p -> tap index p/dil if p is a multiple of dil and in range.
+__device__ __forceinline__ int tap_src(int p, int dil, int k) {
+  const int t = p / dil;
+  return (t * dil == p && t < k) ? t : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward passes on one sequence whose P inputs per thread are already in registers;
+// leaves the natural-order spectrum in lseq.  Contains two barriers: every thread of the
+// workgroup must call it (idle threads pass act = false).
+template <class G>
+__device__ __forceinline__ void fwd_from_regs(float (&re)[G::P], float (&im)[G::P], float2* lseq, int tseq, bool act,
+                                              BufRsrc twA, BufRsrc twB) {
+  if (act) {
+    fft_regs<G::P, -1>(re, im);
+    passA_twiddle_store<G, -1>(re, im, lseq, tseq, twA);
+  }
+  __syncthreads();
+  if (act) passB_load<G>(re, im, lseq, tseq);
+  __syncthreads();
+  if (act) {
+    const int j = passB_compute<G, -1>(re, im, tseq, twB);
+    const int k1 = tseq >> G::LGS;
+    float2* dst = lseq + G::nat(k1 + G::P * G::P * j);
+#pragma unroll
+    for (int k = 0; k < G::P; ++k) dst[G::P * k] = make_float2(re[k], im[k]);
+  }
+}
+
+// inverse passes from the natural-order spectrum in lseq; on return element k of this lane is
+// sample n = o1 + P*k + P*P*j (o1 = tseq >> log2 S, j returned).  Two barriers inside.
+template <class G>
+__device__ __forceinline__ int inv_to_regs(float (&re)[G::P], float (&im)[G::P], float2* lseq, int tseq, bool act,
+                                           BufRsrc twA, BufRsrc twB) {
+  if (act) {
+#pragma unroll
+    for (int i1 = 0; i1 < G::P; ++i1) {
+      const float2 v = lseq[G::nat(G::N2 * i1 + tseq)];
+      re[i1] = v.x; im[i1] = v.y;
+    }
+  }
+  __syncthreads();
+  if (act) {
+    fft_regs<G::P, +1>(re, im);
+    passA_twiddle_store<G, +1>(re, im, lseq, tseq, twA);
+  }
+  __syncthreads();
+  int j = 0;
+  if (act) {
+    passB_load<G>(re, im, lseq, tseq);
+    j = passB_compute<G, +1>(re, im, tseq, twB);
+  }
+  return j;
+}
+
+template <class G>
+struct SeqLayout {
+  // sequence stride in LDS: == 2 (mod 32) complex slots so that 16 neighbouring sequences read
+  // at the same bin hit 16 different bank pairs (transposed stores / tile loads)
+  static constexpr int LSEQP = G::LSEQ + ((2 - G::LSEQ % 32) + 32) % 32;
+};
+
+// ------------------------------------------------------------------------------------------ rows_r2c
+struct RowsR2CArgs {
+  const float* src;      // signal (B, C, [Z,] Y, X) or kernel taps (Co, Cig, [Kz,] Ky, Kx)
+  float2* dst;           // [(a*NC + c)][Fx][NYa]
+  const float2* twA;
+  const float2* twB;
+  int from_kernel;       // 0: signal with padding maps, 1: dilated kernel taps
+  AxisMap mx, my, mz;    // signal: per-axis padding maps (mz unused for 2-D)
+  int kx, ky, kz, dx, dy, dz;   // kernel: taps and dilation per axis
+  int NA, NC, NY, NYa;   // images, planes per image (padded), rows per plane (padded), row stride of dst
+  int SZ, SY, SX;        // source extents (signal: unpadded sizes; kernel: taps)
+  int Fx;                // T/2 + 1
+};
+
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  constexpr int RB = 2 * NSEQ;
+  static_assert(NT == NSEQ * G::TS, "one thread slot per sequence point group");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int nyb = (a.NY + RB - 1) / RB;
+  int id = blockIdx.x;
+  const int yb = id % nyb; id /= nyb;
+  const int c = id % a.NC;
+  const int img = id / a.NC;
+  const int y0 = yb * RB;
+
+  float re[P], im[P];
+  {
+    // two rows per sequence
+    const float* rows[2];
+    bool ok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int yp = y0 + 2 * sq + h;
+      int ys, zs;
+      if (a.from_kernel) {
+        ys = yp < a.NY ? tap_src(yp, a.dy, a.ky) : -1;
+        zs = tap_src(c, a.dz, a.kz);
+      } else {
+        ys = yp < a.NY ? axis_src(a.my, yp) : -1;
+        zs = a.NC > 1 ? axis_src(a.mz, c) : 0;
+      }
+      ok[h] = ys >= 0 && zs >= 0;
+      rows[h] = a.src + (((size_t)img * a.SZ + (ok[h] ? zs : 0)) * a.SY + (ok[h] ? ys : 0)) * a.SX;
+    }
+    float2* col = lds + sq * LSEQP + tseq;
+#pragma unroll 1
+    for (int n1 = 0; n1 < P; ++n1) {
+      const int xp = G::N2 * n1 + tseq;
+      const int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
+      const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
+      const float v1 = (ok[1] && xs >= 0) ? rows[1][xs] : 0.f;
+      col[n1 * G::RS] = make_float2(v0, v1);
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < P; ++n1) {
+      const float2 v = col[n1 * G::RS];
+      re[n1] = v.x; im[n1] = v.y;
+    }
+  }
+  fwd_from_regs<G>(re, im, lds + sq * LSEQP, tseq, true, twA, twB);
+  __syncthreads();
+  // unpack the two real spectra of every pair and store transposed: RB rows contiguous per bin
+  float2* out = a.dst + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+  for (int idx = tid; idx < a.Fx * RB; idx += NT) {
+    const int r = idx % RB, fx = idx / RB;
+    if (y0 + r >= a.NY) continue;
+    const float2* z = lds + (r >> 1) * LSEQP;
+    const float2 zf = z[G::nat(fx)], zg = z[G::nat((T - fx) & (T - 1))];
+    float2 v;
+    if ((r & 1) == 0) v = make_float2(0.5f * (zf.x + zg.x), 0.5f * (zf.y - zg.y));
+    else v = make_float2(0.5f * (zf.y + zg.y), 0.5f * (zg.x - zf.x));
+    out[(size_t)fx * a.NYa + r] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ c2c_fwd
+struct C2CArgs {
+  const float2* src;
+  float2* dst;
+  const float2* twA;
+  const float2* twB;
+  // sequence (a, c, bn): src element n at a*sa + c*sc + bn*sb + n        (n < NLEN, zero beyond)
+  // dst: transposed  a*ta + c*tc + f*tf + bn   (store_mode 0, forward)
+  //      weights     final kernel-spectrum layout (store_mode 1, forward; conj + scale + i-pair interleave)
+  //      inverse     src transposed a*sa + c*sc + f*sb + bn ; dst a*ta + bn*tb + c*tc + n_out
+  long long sa, sc, sb, ta, tc, tf, tb;
+  int NA, NC, NB, NLEN;
+  int store_mode;
+  // weights mode: a = o*Cig + i (o over all Cout)
+  int Cig, Cog, Cig_pad, Cog_pad;
+  float scale;
+  // inverse mode: valid samples and decimation
+  int NV, stride;
+};
+
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  static_assert(NT == NSEQ * G::TS, "thread count");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int nbb = (a.NB + NSEQ - 1) / NSEQ;
+  int id = blockIdx.x;
+  const int bb = id % nbb; id /= nbb;
+  const int c = id % a.NC;
+  const int img = id / a.NC;
+  const int bn0 = bb * NSEQ;
+  const bool act = bn0 + sq < a.NB;
+
+  float re[P], im[P];
+  {
+    const float2* s = a.src + (size_t)img * a.sa + (size_t)c * a.sc + (size_t)(bn0 + sq) * a.sb;
+#pragma unroll
+    for (int n1 = 0; n1 < P; ++n1) {
+      const int n = G::N2 * n1 + tseq;
+      float2 v = make_float2(0.f, 0.f);
+      if (act && n < a.NLEN) v = s[n];
+      re[n1] = v.x; im[n1] = v.y;
+    }
+  }
+  fwd_from_regs<G>(re, im, lds + sq * LSEQP, tseq, act, twA, twB);
+  __syncthreads();
+  if (a.store_mode == 0) {
+    float2* out = a.dst + (size_t)img * a.ta + (size_t)c * a.tc + bn0;
+    for (int idx = tid; idx < T * NSEQ; idx += NT) {
+      const int r = idx % NSEQ, f = idx / NSEQ;
+      if (bn0 + r < a.NB) out[(size_t)f * a.tf + r] = lds[r * LSEQP + G::nat(f)];
+    }
+  } else {
+    // kernel spectrum: H = conj(W_hat) * scale, layout [g][o][i/2][col][f][i&1]; here bn indexes the
+    // columns (fx or (fx,fy)) of one (o, i) image and c is unused (NC == 1)
+    const int o_all = img / a.Cig, i = img % a.Cig;
+    const int g = o_all / a.Cog, o = o_all % a.Cog;
+    float2* base = a.dst + (((size_t)(g * a.Cog_pad + o) * (a.Cig_pad / 2) + (i >> 1)) * a.NB) * T * 2 + (i & 1);
+    for (int idx = tid; idx < T * NSEQ; idx += NT) {
+      const int f = idx % T, r = idx / T;
+      if (bn0 + r < a.NB) {
+        const float2 v = lds[r * LSEQP + G::nat(f)];
+        base[((size_t)(bn0 + r) * T + f) * 2] = make_float2(v.x * a.scale, -v.y * a.scale);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ c2c_inv
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  static_assert(NT == NSEQ * G::TS, "thread count");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int nbb = (a.NB + NSEQ - 1) / NSEQ;
+  int id = blockIdx.x;
+  const int bb = id % nbb; id /= nbb;
+  const int c = id % a.NC;
+  const int img = id / a.NC;
+  const int bn0 = bb * NSEQ;
+  const bool act = bn0 + sq < a.NB;
+  {
+    const float2* in = a.src + (size_t)img * a.sa + (size_t)c * a.sc + bn0;
+    for (int idx = tid; idx < T * NSEQ; idx += NT) {
+      const int r = idx % NSEQ, f = idx / NSEQ;
+      float2 v = make_float2(0.f, 0.f);
+      if (bn0 + r < a.NB) v = in[(size_t)f * a.sb + r];
+      lds[r * LSEQP + G::nat(f)] = v;
+    }
+  }
+  __syncthreads();
+  float re[P], im[P];
+  const int j = inv_to_regs<G>(re, im, lds + sq * LSEQP, tseq, act, twA, twB);
+  if (act) {
+    float2* out = a.dst + (size_t)img * a.ta + (size_t)(bn0 + sq) * a.tb + (size_t)c * a.tc;
+    const int nbase = (tseq >> G::LGS) + P * P * j;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const int n = nbase + P * k;
+      const int idx = n / a.stride;
+      if (n < a.NV && idx * a.stride == n) out[idx] = make_float2(re[k], im[k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ rows_c2r
+struct RowsC2RArgs {
+  const float2* src;     // [(a*NC + c)][Fx][NYa]  (a = b*Cout + o)
+  float* dst;            // (B, Cout, [Zo,] Yo, Xo)
+  const float* bias;
+  const float2* twA;
+  const float2* twB;
+  int NA, NC, NY, NYa, Fx, Cout;
+  int NV, stride, Xo;    // valid stride-1 samples along x, decimation, output row length
+};
+
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  constexpr int RB = 2 * NSEQ;
+  static_assert(NT == NSEQ * G::TS, "thread count");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int nyb = (a.NY + RB - 1) / RB;
+  int id = blockIdx.x;
+  const int yb = id % nyb; id /= nyb;
+  const int c = id % a.NC;
+  const int img = id / a.NC;
+  const int y0 = yb * RB;
+  {
+    // rows 2s (-> real part) and 2s+1 (-> imaginary part) share one complex inverse FFT:
+    // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
+    const float2* in = a.src + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+    for (int idx = tid; idx < a.Fx * NSEQ; idx += NT) {
+      const int s = idx % NSEQ, fx = idx / NSEQ;
+      float2 ya = make_float2(0.f, 0.f), yb2 = make_float2(0.f, 0.f);
+      if (y0 + 2 * s < a.NY) ya = in[(size_t)fx * a.NYa + 2 * s];
+      if (y0 + 2 * s + 1 < a.NY) yb2 = in[(size_t)fx * a.NYa + 2 * s + 1];
+      float2* z = lds + s * LSEQP;
+      if (fx == 0 || fx == T / 2) {
+        z[G::nat(fx)] = make_float2(ya.x, yb2.x);          // both spectra are real at the self-paired bins
+      } else {
+        z[G::nat(fx)] = make_float2(ya.x - yb2.y, ya.y + yb2.x);
+        z[G::nat(T - fx)] = make_float2(ya.x + yb2.y, yb2.x - ya.y);
+      }
+    }
+  }
+  __syncthreads();
+  float re[P], im[P];
+  const int j = inv_to_regs<G>(re, im, lds + sq * LSEQP, tseq, true, twA, twB);
+  const int ya_row = y0 + 2 * sq;
+  const float b = a.bias ? a.bias[img % a.Cout] : 0.f;
+  float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;
+  float* o1 = o0 + a.Xo;
+  const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;
+  const int nbase = (tseq >> G::LGS) + P * P * j;
+#pragma unroll
+  for (int k = 0; k < P; ++k) {
+    const int n = nbase + P * k;
+    const int idx = n / a.stride;
+    if (n < a.NV && idx * a.stride == n) {
+      if (has0) o0[idx] = re[k] + b;
+      if (has1) o1[idx] = im[k] + b;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ fusedc
+// Outermost-axis pass: CIB complex sequences (one per input channel of the group) per workgroup.
+struct FusedCArgs {
+  const float2* src;     // [(b*Cin + ci)][col][NLEN]   contiguous along the fused axis
+  const float4* wspec;   // [g][Cog_pad][Cig_pad/2][ncol][T] float4 = {H(o,2ip), H(o,2ip+1)}
+  float2* dst;           // [(b*Cout + co)][col][NVo]    valid (decimated) samples
+  const float2* twA;
+  const float2* twB;
+  int B, Cin, Cout, G, Cig, Cog, Cig_pad, Cog_pad, cob, n_ochunks;
+  int ncol, NLEN;        // columns per image, valid input length (zero beyond)
+  int Kd, V, ntiles, Lfull, NVo, stride;
+  int accumulate;
+};
+
+template <int P, int S, int CIB, int NT>
+__global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  static_assert(NT == CIB * G::TS, "one sequence per channel of the chunk");
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+
+  // id = ((((b*ntiles + tile)*n_ochunks + oc)*G + g)*ncol + col): neighbouring workgroups share (g, oc)
+  // weights of neighbouring columns
+  int id = blockIdx.x;
+  const int col = id % a.ncol; id /= a.ncol;
+  const int g = id % a.G; id /= a.G;
+  const int oc = id % a.n_ochunks; id /= a.n_ochunks;
+  const int tile = id % a.ntiles;
+  const int b = id / a.ntiles;
+
+  float2* zin = lds;
+  float2* vout = a.accumulate ? lds + CIB * LSEQP : lds;
+  const int n_ichunks = a.Cig_pad / CIB;
+  const int t0 = tile * a.V;
+  const size_t wcol = (size_t)a.ncol * T;                          // float4 per (o, ip)
+  const float4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)col * T;
+
+  for (int ic = 0; ic < n_ichunks; ++ic) {
+    {
+      const int ci = ic * CIB + sq;
+      const bool has = ci < a.Cig;
+      const float2* s = a.src + (((size_t)b * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
+      float re[P], im[P];
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int n = G::N2 * n1 + tseq;
+        float2 v = make_float2(0.f, 0.f);
+        if (has && t0 + n < a.NLEN) v = s[n];
+        re[n1] = v.x; im[n1] = v.y;
+      }
+      fwd_from_regs<G>(re, im, zin + sq * LSEQP, tseq, true, twA, twB);
+    }
+    __syncthreads();
+    // mix: every bin is independent in complex mode
+    for (int f = tid; f < T; f += NT) {
+      float xr[CIB], xi[CIB];
+#pragma unroll
+      for (int i = 0; i < CIB; ++i) {
+        const float2 z = zin[i * LSEQP + G::nat(f)];
+        xr[i] = z.x; xi[i] = z.y;
+      }
+#pragma unroll 1
+      for (int o = 0; o < a.cob; ++o) {
+        const float4* w = wgrp + ((size_t)(oc * a.cob + o) * (a.Cig_pad / 2) + ic * (CIB / 2)) * wcol + f;
+        float yr = 0.f, yi = 0.f;
+#pragma unroll
+        for (int p = 0; p < CIB / 2; ++p) {
+          const float4 h = w[(size_t)p * wcol];
+          yr = fmaf(xr[2 * p], h.x, yr); yr = fmaf(-xi[2 * p], h.y, yr);
+          yi = fmaf(xr[2 * p], h.y, yi); yi = fmaf(xi[2 * p], h.x, yi);
+          yr = fmaf(xr[2 * p + 1], h.z, yr); yr = fmaf(-xi[2 * p + 1], h.w, yr);
+          yi = fmaf(xr[2 * p + 1], h.w, yi); yi = fmaf(xi[2 * p + 1], h.z, yi);
+        }
+        float2* pv = vout + o * LSEQP + G::nat(f);
+        if (ic != 0) { const float2 old = *pv; yr += old.x; yi += old.y; }
+        *pv = make_float2(yr, yi);
+      }
+    }
+    __syncthreads();
+  }
+  // inverse + store of the valid, decimated samples
+  float re[P], im[P];
+  const bool act = sq < a.cob;
+  const int j = inv_to_regs<G>(re, im, vout + sq * LSEQP, tseq, act, twA, twB);
+  const int co = oc * a.cob + sq;
+  if (act && co < a.Cog) {
+    float2* out = a.dst + (((size_t)b * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
+    const int limit = min(a.V, a.Lfull - t0);
+    const int nbase = (tseq >> G::LGS) + P * P * j;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const int n = nbase + P * k;
+      const int t = t0 + n;
+      const int idx = t / a.stride;
+      if (n < limit && idx * a.stride == t) out[idx] = make_float2(re[k], im[k]);
+    }
+  }
+}
+
+}  // namespace fc

@@ -4,11 +4,18 @@
 #include "fc_internal.h"
 
 #ifndef FC_P
-#error "compile with -DFC_P=<points per thread> -DFC_S=<lane split> -DFC_NT=<threads>"
+#error "compile with -DFC_P=<points per thread> -DFC_S=<lane split> -DFC_NT=<threads of the fused 1-D kernel>"
 #endif
 
 namespace fc {
 namespace {
+
+using GG = Geo<FC_P, FC_S>;
+constexpr int kT = GG::T;
+constexpr int kNSEQ_C = (8192 / kT) > 16 ? 16 : ((8192 / kT) < 2 ? 2 : (8192 / kT));
+constexpr int kNSEQ_R = kNSEQ_C / 2;
+constexpr int kLSEQP = SeqLayout<GG>::LSEQP;
+constexpr int kFusedMaxCib = (8 * kLSEQP * 8 <= 160 * 1024 && 8 * GG::TS <= 1024) ? 8 : 4;
 
 // Opt in to > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup).  Done once per
 // kernel with the full 160 KiB so nothing but the launch happens on later calls
@@ -50,13 +57,91 @@ hipError_t spec1d_dispatch(const Spec1dArgs& a, int grid, size_t lds, hipStream_
   return hipGetLastError();
 }
 
+hipError_t rows_r2c_dispatch(const RowsR2CArgs& a, hipStream_t st) {
+  constexpr int NT = kNSEQ_R * GG::TS;
+  auto k = rows_r2c_kernel<FC_P, FC_S, kNSEQ_R, NT>;
+  const size_t lds = (size_t)kNSEQ_R * kLSEQP * sizeof(float2);
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
+  const long long grid = (long long)a.NA * a.NC * nyb;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+
+template <bool INV>
+hipError_t c2c_dispatch(const C2CArgs& a, hipStream_t st) {
+  constexpr int NT = kNSEQ_C * GG::TS;
+  const size_t lds = (size_t)kNSEQ_C * kLSEQP * sizeof(float2);
+  const long long nbb = (a.NB + kNSEQ_C - 1) / kNSEQ_C;
+  const long long grid = (long long)a.NA * a.NC * nbb;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  static bool done = false;
+  if (INV) {
+    auto k = c2c_inv_kernel<FC_P, FC_S, kNSEQ_C, NT>;
+    hipError_t e = ensure_lds(k, lds, &done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  } else {
+    auto k = c2c_fwd_kernel<FC_P, FC_S, kNSEQ_C, NT>;
+    hipError_t e = ensure_lds(k, lds, &done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t rows_c2r_dispatch(const RowsC2RArgs& a, hipStream_t st) {
+  constexpr int NT = kNSEQ_R * GG::TS;
+  auto k = rows_c2r_kernel<FC_P, FC_S, kNSEQ_R, NT>;
+  const size_t lds = (size_t)kNSEQ_R * kLSEQP * sizeof(float2);
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
+  const long long grid = (long long)a.NA * a.NC * nyb;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+
+template <int CIB>
+hipError_t launch_fusedc(const FusedCArgs& a, hipStream_t st) {
+  if constexpr (CIB > kFusedMaxCib) {
+    return hipErrorInvalidValue;
+  } else {
+    constexpr int NT = CIB * GG::TS;
+    auto k = fusedc_kernel<FC_P, FC_S, CIB, NT>;
+    const size_t lds = (size_t)(a.accumulate ? 2 : 1) * CIB * kLSEQP * sizeof(float2);
+    static bool done = false;
+    hipError_t e = ensure_lds(k, lds, &done);
+    if (e != hipSuccess) return e;
+    const long long grid = (long long)a.B * a.ntiles * a.n_ochunks * a.G * a.ncol;
+    if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+    return hipGetLastError();
+  }
+}
+
+hipError_t fusedc_dispatch(int cib, const FusedCArgs& a, hipStream_t st) {
+  switch (cib) {
+    case 2: return launch_fusedc<2>(a, st);
+    case 4: return launch_fusedc<4>(a, st);
+    case 8: return launch_fusedc<8>(a, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 }  // namespace
 
 #define FC_CAT_(a, b, c, d) a##b##c##d
 #define FC_CAT(a, b, c, d) FC_CAT_(a, b, c, d)
 const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
-  static const TileImpl impl = {Geo<FC_P, FC_S>::T, FC_P, FC_S, FC_NT, Geo<FC_P, FC_S>::LSEQ,
-                                conv1d_dispatch, spec1d_dispatch};
+  static const TileImpl impl = {kT, FC_P, FC_S, FC_NT, GG::LSEQ, kLSEQP, kNSEQ_C, kNSEQ_R,
+                                conv1d_dispatch, spec1d_dispatch, rows_r2c_dispatch, c2c_dispatch<false>,
+                                c2c_dispatch<true>, rows_c2r_dispatch, fusedc_dispatch, kFusedMaxCib};
   return &impl;
 }
 

@@ -38,7 +38,9 @@ class KernelSpectrum:
         self.plan, self.buf, self.workspace = plan, buf, workspace
 
 
-def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=0):
+def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=None):
+    if tile_hint is None:   # debugging / tuning knob: force the FFT tile length
+        tile_hint = int(os.environ.get("FFTCONV_TILE", "0"))
     n = signal.ndim - 2
     if n < 1 or n > 3:
         raise ValueError(f"fft_conv expects (batch, channels, *spatial) with 1-3 spatial dims, got shape {tuple(signal.shape)}")
@@ -115,8 +117,7 @@ def fft_conv(
     input raises ``ValueError`` (torch's behaviour) instead of returning a
     wrongly shaped tensor.
     """
-    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode,
-                     tile_hint=int(os.environ.get("FFTCONV_TILE", "0")))
+    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode)
     spectrum = transform_kernel(plan, kernel)     # the reference also re-transforms per call (functional.py:71)
     return _forward_native(signal, spectrum, bias)
 

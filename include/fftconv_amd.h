@@ -90,6 +90,12 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
 int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
                void* workspace, void* hip_stream);
 
+/* Profiling hook (not part of the drop-in surface): when a device buffer of
+ * 16 * fc_debug_grid(plan) uint64 is set, lane 0 of every workgroup of the fused
+ * 1-D kernel stores the 100 MHz wall clock at its phase boundaries.  NULL = off. */
+int fc_debug_set_stamps(fc_plan* plan, void* device_buffer);
+long long fc_debug_grid(const fc_plan* plan);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-phase timeline of the fused 1-D kernel from its timestamp hook (fc_debug_set_stamps).
+
+Diagnostic only: the stamped launch drains loads at two extra points, so read SHARES, not totals."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fft_conv_pytorch_amd as fca  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--ch", type=int, default=8)
+ap.add_argument("--len", type=int, default=32768)
+ap.add_argument("--k", type=int, default=512)
+ap.add_argument("--tile", type=int, default=0)
+args = ap.parse_args()
+if args.tile:
+    os.environ["FFTCONV_TILE"] = str(args.tile)
+dev = "cuda:0"
+layer = fca.FFTConv1d(args.ch, args.ch, args.k).to(dev)
+x = torch.randn(args.batch, args.ch, args.len, device=dev)
+for _ in range(3):
+    y = layer(x)
+plan = layer.__dict__["_spectrum_cache"][1].plan
+grid = plan.debug_grid()
+buf = torch.zeros(grid * 16, dtype=torch.int64, device=dev)
+plan.debug_set_stamps(buf.data_ptr())
+torch.cuda.synchronize()
+y = layer(x)
+torch.cuda.synchronize()
+plan.debug_set_stamps(None)
+st = buf.cpu().numpy().reshape(grid, 16).astype(np.float64) * 0.01   # 100 MHz ticks -> microseconds
+t0 = st[:, 0].min()
+names = ["start", "input landed", "passA done", "barrier1", "passB done", "barrier3", "mix done", "barrier4",
+         "invA done", "barrier6", "stores issued", "stores landed"]
+print(f"grid={grid} tile={plan.tile}  kernel span = {st[:, 11].max() - t0:.2f} us")
+print(f"{'phase':16s} {'median dt':>10s} {'p10':>8s} {'p90':>8s}   (us, per workgroup, lane 0 of wave 0)")
+for i in range(1, 12):
+    dt = st[:, i] - st[:, i - 1]
+    print(f"{names[i]:16s} {np.median(dt):10.2f} {np.percentile(dt, 10):8.2f} {np.percentile(dt, 90):8.2f}")
+life = st[:, 11] - st[:, 0]
+print(f"workgroup lifetime median {np.median(life):.2f} us; start times: p50 {np.median(st[:, 0] - t0):.2f} "
+      f"p90 {np.percentile(st[:, 0] - t0, 90):.2f} max {(st[:, 0] - t0).max():.2f} us")
+hist, edges = np.histogram(st[:, 0] - t0, bins=10)
+print("start-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))

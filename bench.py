@@ -116,7 +116,7 @@ def main():
         layer.weight.normal_()
         layer.bias.normal_()
     layer = layer.to(dev)
-    if world > 1:   # the path's only exchange: weights from rank 0 (RCCL broadcast over xGMI)
+    if world > 1:   # every rank holds the same parameters (as after loading one checkpoint)
         dist.broadcast(layer.weight.data, src=0)
         dist.broadcast(layer.bias.data, src=0)
 
@@ -135,6 +135,10 @@ def main():
 
     spectrum = layer.__dict__["_spectrum_cache"][1]
     plan = spectrum.plan
+    if world > 1:
+        # the path's only exchange: rank 0 transforms the kernel, RCCL broadcasts the spectrum over xGMI
+        from fft_conv_pytorch_amd.distributed import broadcast_kernel_spectrum
+        spectrum = broadcast_kernel_spectrum(plan, layer.weight.detach(), src=0)
     bias_ptr = layer.bias.data_ptr()
     stream = torch.cuda.current_stream(dev)
 

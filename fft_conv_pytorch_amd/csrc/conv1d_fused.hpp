@@ -173,35 +173,18 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;   // bytes between output channels
       const unsigned wbase = (unsigned)(oc * a.cob) * ostride + (unsigned)(ic * NPI) * (T / 2) * 16u;
       constexpr int FB = (T / 2 >= 2 * NT) ? 2 : 1;   // bin pairs per thread per iteration
-      if (tid == 0) {
-        // bins 0 and T/2 are self-paired and both spectra are real there;
-        // wspec[.][f=0] holds {Re H[0], Re H[T/2]} per input channel.
-        float x0[CIB], xh[CIB];
+      // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
+      // lane (output o, bin) of wave 0 owns one real output; its loads are issued here and consumed
+      // after the main loop so their latency is hidden.
+      const int sb_o = tid >> 1, sb_f = (tid & 1) ? T / 2 : 0;
+      const bool sb_act = tid < 2 * a.cob;
+      float4 sbw[NPI];
+      float2 sbz[NPI];
+      if (sb_act) {
 #pragma unroll
         for (int p = 0; p < NPI; ++p) {
-          const float2 z0 = zin[p * G::LSEQ + G::nat(0)];
-          const float2 zh = zin[p * G::LSEQ + G::nat(T / 2)];
-          x0[2 * p] = 2.f * z0.x; x0[2 * p + 1] = 2.f * z0.y;
-          xh[2 * p] = 2.f * zh.x; xh[2 * p + 1] = 2.f * zh.y;
-        }
-#pragma unroll 1
-        for (int q = 0; q < npo; ++q) {
-          float a0 = 0.f, b0 = 0.f, ah = 0.f, bh = 0.f;
-          const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-#pragma unroll
-          for (int p = 0; p < NPI; ++p) {
-            const float4 ha = buf_load_f32x4(wg, 0u, sa + p * (T / 2) * 16);
-            const float4 hb = buf_load_f32x4(wg, 0u, sb + p * (T / 2) * 16);
-            a0 = fmaf(x0[2 * p], ha.x, a0); a0 = fmaf(x0[2 * p + 1], ha.z, a0);
-            ah = fmaf(xh[2 * p], ha.y, ah); ah = fmaf(xh[2 * p + 1], ha.w, ah);
-            b0 = fmaf(x0[2 * p], hb.x, b0); b0 = fmaf(x0[2 * p + 1], hb.z, b0);
-            bh = fmaf(xh[2 * p], hb.y, bh); bh = fmaf(xh[2 * p + 1], hb.w, bh);
-          }
-          float2 v0 = make_float2(a0, b0), vh = make_float2(ah, bh);
-          float2* p0 = vout + q * G::LSEQ + G::nat(0);
-          float2* ph = vout + q * G::LSEQ + G::nat(T / 2);
-          if (ic != 0) { const float2 o0 = *p0, oh = *ph; v0.x += o0.x; v0.y += o0.y; vh.x += oh.x; vh.y += oh.y; }
-          *p0 = v0; *ph = vh;
+          sbw[p] = buf_load_f32x4(wg, (unsigned)sb_o * ostride, wbase + p * (T / 2) * 16);
+          sbz[p] = zin[p * G::LSEQ + G::nat(sb_f)];
         }
       }
 #pragma unroll 1
@@ -253,6 +236,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
             }
           }
         }
+      }
+      if (sb_act) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          acc = fmaf(2.f * sbz[p].x, (tid & 1) ? sbw[p].y : sbw[p].x, acc);
+          acc = fmaf(2.f * sbz[p].y, (tid & 1) ? sbw[p].w : sbw[p].z, acc);
+        }
+        float* dstf = reinterpret_cast<float*>(vout + (sb_o >> 1) * G::LSEQ + G::nat(sb_f)) + (sb_o & 1);
+        if (ic != 0) acc += *dstf;
+        *dstf = acc;
       }
     }
     stamp(a.stamps, 6);

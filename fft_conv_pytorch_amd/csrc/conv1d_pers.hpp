@@ -1,0 +1,304 @@
+// conv1d_pers.hpp -- persistent fused 1-D FFT convolution, NB batch items per workgroup.
+//
+// Same arithmetic as conv1d_fused.hpp (which stays the general fallback), organised for throughput:
+//   * a workgroup is resident for the whole launch and walks a host-built work list; a work item is
+//     (tile, group, out-chunk, first batch item, number of batch items <= NB);
+//   * the NB batch items of an item share every kernel-spectrum load of the mix step, which is what
+//     bounds the one-item-per-workgroup kernel (L2 -> L1 traffic of the spectrum);
+//   * the pass-A twiddle table lives in LDS for the lifetime of the workgroup;
+//   * the mix streams the spectrum through a two-deep register pipeline (loads of step s+1 are in
+//     flight while step s is contracted).
+// Fast-path restrictions (everything else runs conv1d_fused_kernel): a single input-channel chunk
+// (Cin/groups <= CIB), full output chunks (Cout/groups a multiple of CIB) and stride 1.
+#pragma once
+#include "conv1d_fused.hpp"
+
+namespace fc {
+
+struct WorkItem {
+  int b0, nbc, tile, goc;   // goc = g * n_ochunks + oc
+};
+
+struct Conv1dPersArgs {
+  Conv1dArgs c;
+  const WorkItem* items;
+  int n_items;
+  int debug_mode;   // experiments: 1 = mix without spectrum loads, 2 = mix without contraction, 3 = no LDS traffic in mix
+};
+
+template <class G, int DIR>
+__device__ __forceinline__ void passA_twiddle_store_lds(float (&re)[G::P], float (&im)[G::P], float2* __restrict__ lseq,
+                                                        int n2, const float2* __restrict__ twl) {
+  lseq[n2] = make_float2(re[0], im[0]);
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) {
+    const float2 w = twl[k1 * G::N2 + n2];
+    const float c = w.x, s = (DIR > 0) ? -w.y : w.y;
+    const float xr = re[k1], xi = im[k1];
+    lseq[k1 * G::RS + n2] = make_float2(fmaf(c, xr, -s * xi), fmaf(c, xi, s * xr));
+  }
+}
+
+__device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, int slot) {
+  if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
+template <int P, int S, int CIB, int NB, int NT, int MIXDEPTH = 4>
+__global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int NPI = CIB / 2;
+  constexpr int NSEQ = NB * NPI;
+  static_assert(NT == NSEQ * G::TS, "one thread slot per point group of every sequence");
+  static_assert((T / 2) % NT == 0, "bin pairs divide evenly over the threads");
+  constexpr int BP = (T / 2) / NT;          // bin pairs per thread
+  constexpr int TWN = P * G::N2;            // pass-A twiddle table entries
+  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  const Conv1dArgs& a = pa.c;
+
+  const int tid = threadIdx.x;
+  const int sq = tid / G::TS;               // sequence slot: batch slot nb, channel pair p
+  const int tseq = tid % G::TS;
+  const int nb = sq / NPI, pr = sq % NPI;
+  constexpr int npo = NPI;                  // full output chunks only
+  float2* twl = lds;
+  float2* zbuf = lds + TWN;                 // [NSEQ][LSEQ]
+  float2* zseq = zbuf + sq * G::LSEQ;
+
+  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const PadMap pm = make_padmap(a.pad_mode, a.L);
+  const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
+  __syncthreads();
+
+  for (int it = blockIdx.x; it < pa.n_items; it += gridDim.x) {
+    const WorkItem wi = pa.items[it];
+    const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
+    const int tile = wi.tile;
+    const int tile_pos = tile * a.V - a.pad;
+    const bool interior = (tile_pos >= 0) && (tile_pos + T <= a.L);
+    const bool act_in = nb < wi.nbc;
+    // descriptor over the NB batch items' slab of this group: uniform base, lane part in the offset
+    const float* xbase = a.x + ((size_t)wi.b0 * a.Cin + (size_t)g * a.Cig) * a.L;
+    const BufRsrc xg = make_rsrc(xbase, (unsigned)(((size_t)(wi.nbc - 1) * a.Cin + a.Cig) * a.L * 4));
+    const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
+
+    stamp_item(a.stamps, it, 0);
+    // bias of this lane's two output channels, requested now and used in the last pass
+    const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
+    const float bias0 = a.bias ? a.bias[cg0] : 0.f;
+    const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
+    // ------------------------------------------------ forward pass A
+    {
+      float re[P], im[P];
+      const int ci0 = 2 * pr;
+      const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
+      if (interior && has1) {
+        const unsigned v0 = (((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L + (unsigned)(tile_pos + tseq)) * 4u;
+        const unsigned v1 = v0 + (unsigned)a.L * 4u;
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          re[n1] = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+          im[n1] = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+        }
+      } else {
+        const float* r0 = xbase + ((size_t)(act_in ? nb : 0) * a.Cin + (has0 ? ci0 : 0)) * a.L;
+        const float* r1 = has1 ? r0 + a.L : r0;
+        float2* col = zseq + tseq;
+#pragma unroll 1
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int pos = tile_pos + G::N2 * n1 + tseq;
+          col[n1 * G::RS] = make_float2(load_padded(r0, pos, a.L, a.pad, pm, has0),
+                                        load_padded(r1, pos, a.L, a.pad, pm, has1));
+        }
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const float2 v = col[n1 * G::RS];
+          re[n1] = v.x; im[n1] = v.y;
+        }
+      }
+      if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
+      if (act_in) {
+        fft_regs<P, -1>(re, im);
+        passA_twiddle_store_lds<G, -1>(re, im, zseq, tseq, twl);
+      }
+    }
+    stamp_item(a.stamps, it, 2);
+    __syncthreads();
+    stamp_item(a.stamps, it, 3);
+    // ------------------------------------------------ forward pass B
+    {
+      float re[P], im[P];
+      if (act_in) passB_load<G>(re, im, zseq, tseq);
+      __syncthreads();
+      if (act_in) {
+        const int j = passB_compute<G, -1>(re, im, tseq, twB);
+        const int k1 = tseq >> G::LGS;
+        float2* dst = zseq + G::nat(k1 + P * P * j);
+#pragma unroll
+        for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+      }
+    }
+    stamp_item(a.stamps, it, 4);
+    __syncthreads();
+    stamp_item(a.stamps, it, 5);
+    // ------------------------------------------------ mix
+    {
+      const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
+      const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
+      // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
+      // lane (batch b, output o, bin) of wave 0 owns one real output.  Its loads are issued here and
+      // consumed after the main loop, so their latency is hidden (a one-lane serial loop cost ~8 us).
+      static_assert(NB * CIB * 2 <= 64, "the self-paired bins are handled by one wave");
+      const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
+      const bool sb_act = tid < NB * CIB * 2 && sb_b < wi.nbc;
+      float4 sbw[NPI];
+      float2 sbz[NPI];
+      if (sb_act) {
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          sbw[p] = buf_load_f32x4(wg, (unsigned)sb_o * ostride, wbase + p * (T / 2) * 16);
+          sbz[p] = zbuf[(sb_b * NPI + p) * G::LSEQ + G::nat(sb_f)];
+        }
+      }
+      // spectrum pipeline: step = (bin pair m, output pair q); the 2*NPI float4 of the next step are
+      // requested before the current step is contracted (two named register sets, static indices)
+      auto issue = [&](int m, int q, float4 (&dst)[2 * NPI]) {
+        const unsigned vo = (unsigned)(tid + m * NT) * 16u;
+        const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+        if (pa.debug_mode == 1) {
+#pragma unroll
+          for (int p = 0; p < 2 * NPI; ++p) dst[p] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+          return;
+        }
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
+          dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
+        }
+      };
+      float xr[NB][CIB], xi[NB][CIB];
+      auto contract = [&](int f, int fm, int q, const float4 (&wc)[2 * NPI]) {
+        if (pa.debug_mode == 2) {
+#pragma unroll
+          for (int p = 0; p < 2 * NPI; ++p) asm volatile("" :: "v"(wc[p].x), "v"(wc[p].y), "v"(wc[p].z), "v"(wc[p].w));
+          return;
+        }
+        if (q < npo) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) {
+              const float4 ha = wc[2 * p], hb = wc[2 * p + 1];
+              yar = fmaf(xr[b][2 * p], ha.x, yar); yar = fmaf(-xi[b][2 * p], ha.y, yar);
+              yai = fmaf(xr[b][2 * p], ha.y, yai); yai = fmaf(xi[b][2 * p], ha.x, yai);
+              yar = fmaf(xr[b][2 * p + 1], ha.z, yar); yar = fmaf(-xi[b][2 * p + 1], ha.w, yar);
+              yai = fmaf(xr[b][2 * p + 1], ha.w, yai); yai = fmaf(xi[b][2 * p + 1], ha.z, yai);
+              ybr = fmaf(xr[b][2 * p], hb.x, ybr); ybr = fmaf(-xi[b][2 * p], hb.y, ybr);
+              ybi = fmaf(xr[b][2 * p], hb.y, ybi); ybi = fmaf(xi[b][2 * p], hb.x, ybi);
+              ybr = fmaf(xr[b][2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[b][2 * p + 1], hb.w, ybr);
+              ybi = fmaf(xr[b][2 * p + 1], hb.w, ybi); ybi = fmaf(xi[b][2 * p + 1], hb.z, ybi);
+            }
+            if (f != 0 && b < wi.nbc) {
+              float2* zb = zbuf + (b * NPI + q) * G::LSEQ;
+              zb[G::nat(f)] = make_float2(yar - ybi, yai + ybr);
+              zb[G::nat(fm)] = make_float2(yar + ybi, ybr - yai);
+            }
+          }
+        }
+      };
+      // Two named register sets (static indices), rolled over the bin pairs.  The walk through
+      // (bin pair, output pair) starts at a different point in every workgroup: all workgroups
+      // stream the same spectrum at the same time, and walking it in lock-step piles every CU's
+      // requests onto the same L2 channels.
+      // Two named register sets (static indices), rolled over the bin pairs: the loads of the next
+      // step are in flight while the current one is contracted.  (Deeper rings were tried: with 256
+      // VGPRs hipcc spills them and the mix gets slower; the mix is bound by the ~70 GB/s per-CU
+      // L2 -> L1 rate, not by latency.)  Workgroups start their walk at different bin pairs.
+      static_assert(NPI % 2 == 0, "pipeline alternates two register sets");
+      float4 wA[2 * NPI], wB[2 * NPI];
+      const int m0 = (int)(blockIdx.x % BP);
+      auto mrot = [&](int m) { const int r = m + m0; return r >= BP ? r - BP : r; };
+      issue(mrot(0), 0, wA);
+#pragma unroll 1
+      for (int mi = 0; mi < BP; ++mi) {
+        const int m = mrot(mi);
+        const int f = tid + m * NT;
+        const int fm = (T - f) & (T - 1);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float2* zb = zbuf + b * NPI * G::LSEQ;
+#pragma unroll
+          for (int p = 0; p < NPI; ++p) {
+            const float2 zf = zb[p * G::LSEQ + G::nat(f)];
+            const float2 zg = zb[p * G::LSEQ + G::nat(fm)];
+            xr[b][2 * p] = zf.x + zg.x;      xi[b][2 * p] = zf.y - zg.y;
+            xr[b][2 * p + 1] = zf.y + zg.y;  xi[b][2 * p + 1] = zg.x - zf.x;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NPI; q += 2) {
+          issue(m, q + 1, wB);
+          contract(f, fm, q, wA);
+          if (q + 2 < NPI) issue(m, q + 2, wA);
+          else if (mi + 1 < BP) issue(mrot(mi + 1), 0, wA);
+          contract(f, fm, q + 1, wB);
+        }
+      }
+      if (sb_act) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          acc = fmaf(2.f * sbz[p].x, (tid & 1) ? sbw[p].y : sbw[p].x, acc);
+          acc = fmaf(2.f * sbz[p].y, (tid & 1) ? sbw[p].w : sbw[p].z, acc);
+        }
+        float* dstf = reinterpret_cast<float*>(zbuf + (sb_b * NPI + (sb_o >> 1)) * G::LSEQ + G::nat(sb_f)) + (sb_o & 1);
+        *dstf = acc;
+      }
+    }
+    stamp_item(a.stamps, it, 6);
+    __syncthreads();
+    stamp_item(a.stamps, it, 7);
+    // ------------------------------------------------ inverse pass A'
+    const bool act_out = act_in && pr < npo;
+    {
+      float re[P], im[P];
+      if (act_out) {
+#pragma unroll
+        for (int i1 = 0; i1 < P; ++i1) {
+          const float2 v = zseq[G::nat(G::N2 * i1 + tseq)];
+          re[i1] = v.x; im[i1] = v.y;
+        }
+      }
+      __syncthreads();
+      if (act_out) {
+        fft_regs<P, +1>(re, im);
+        passA_twiddle_store_lds<G, +1>(re, im, zseq, tseq, twl);
+      }
+    }
+    stamp_item(a.stamps, it, 8);
+    __syncthreads();
+    stamp_item(a.stamps, it, 9);
+    // ------------------------------------------------ inverse pass B' + store
+    if (act_out) {
+      float re[P], im[P];
+      passB_load<G>(re, im, zseq, tseq);
+      const int j = passB_compute<G, +1>(re, im, tseq, twB);
+      const int o1 = tseq >> G::LGS;
+      const int t0 = tile * a.V;
+      const int limit = min(a.V, a.Lfull - t0);
+      const int nbase = o1 + P * P * j;
+      float* y0 = a.y + ((size_t)(wi.b0 + nb) * a.Cout + cg0) * a.Lout + t0 + nbase;
+      float* y1 = y0 + a.Lout;
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        if (nbase + P * k < limit) { y0[P * k] = re[k] + bias0; y1[P * k] = im[k] + bias1; }
+    }
+    stamp_item(a.stamps, it, 10);
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }
+    __syncthreads();   // the sequence buffers are reused by the next item
+  }
+}
+
+}  // namespace fc

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -117,6 +118,10 @@ struct fc_plan {
   int Fx;                     // Tx/2 + 1
   int nd_cob, nd_Cog_pad;
   size_t ws_a, ws_b;          // float2 counts of the two workspace regions
+  // ---- persistent fused 1-D kernel (fast path)
+  int pers_nb;                // batch items per workgroup (0 = fast path not used)
+  int pers_grid, pers_items;
+  fc::WorkItem* d_items;
 };
 
 extern "C" {
@@ -124,6 +129,8 @@ extern "C" {
 int fc_version(void) { return FC_ABI_VERSION; }
 
 const char* fc_last_error(void) { return g_err.c_str(); }
+
+static int plan_1d_persistent(fc_plan* p);
 
 static int plan_1d(fc_plan* p) {
   const fc_desc& d = p->d;
@@ -168,9 +175,54 @@ static int plan_1d(fc_plan* p) {
     return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
   p->spectrum_bytes = per_group * (size_t)d.groups;
   p->workspace_bytes = 0;
-  return get_twiddles(best, &p->tw);
+  int rc = get_twiddles(best, &p->tw);
+  if (rc != FC_OK) return rc;
+  return plan_1d_persistent(p);
 }
 
+
+// Work list of the persistent fused kernel: items of up to NB batch items that share (tile, group,
+// out-chunk), largest first; workgroup w takes items w, w+grid, ...  One workgroup per LDS slot.
+static int plan_1d_persistent(fc_plan* p) {
+  p->pers_nb = 0; p->d_items = nullptr; p->pers_items = 0; p->pers_grid = 0;
+  const fc_desc& d = p->d;
+  const char* env = getenv("FFTCONV_PERS");
+  const int want = env ? atoi(env) : 0;             // 0 off (default while it does not win), -1 auto, n force nb = n
+  if (want == 0) return FC_OK;
+  const fc::TileImpl* t = p->tile;
+  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1) return FC_OK;
+  if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return FC_OK;
+  int dev = 0, cus = 256;
+  FC_HIP(hipGetDevice(&dev));
+  FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t B = d.batch, units = (int64_t)p->ntiles * p->n_ochunks * d.groups;   // per batch item
+  int nb = 0;
+  for (int k = 0; k < 2; ++k) {
+    const int cand = t->pers_nb[k];
+    if (!cand) continue;
+    if (want > 0) { if (cand == want) nb = cand; continue; }
+    // prefer the largest sharing factor that still leaves every CU a workgroup
+    if (cand <= B && (nb == 0 || units * ((B + cand - 1) / cand) >= cus)) nb = cand;
+  }
+  if (nb == 0) return FC_OK;
+  int slot = nb == t->pers_nb[0] ? 0 : 1;
+  const int wgs_per_cu = std::max(1, (int)((160 * 1024) / t->pers_lds[slot]));
+  std::vector<fc::WorkItem> items;
+  const int nfull = (int)(B / nb), rem = (int)(B % nb);
+  for (int pass = 0; pass < 2; ++pass)              // full items first, remainders last
+    for (int tile = 0; tile < p->ntiles; ++tile)
+      for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) {
+        if (pass == 0) for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
+        else if (rem) items.push_back({nfull * nb, rem, tile, goc});
+      }
+  if (items.size() > 0x7fffffffu) return FC_OK;
+  p->pers_items = (int)items.size();
+  p->pers_grid = (int)std::min<int64_t>(p->pers_items, (int64_t)cus * wgs_per_cu);
+  FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
+  FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
+  p->pers_nb = nb;
+  return FC_OK;
+}
 
 static const fc::TileImpl* smallest_tile_at_least(int64_t n) {
   int ntl;
@@ -318,7 +370,11 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   return FC_OK;
 }
 
-void fc_plan_destroy(fc_plan* plan) { delete plan; }
+void fc_plan_destroy(fc_plan* plan) {
+  if (!plan) return;
+  if (plan->d_items) (void)hipFree(plan->d_items);
+  delete plan;
+}
 
 int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]) {
   if (!plan || !out_spatial) return fail(FC_ERR_INVALID, "null argument");
@@ -338,6 +394,7 @@ int fc_debug_set_stamps(fc_plan* plan, void* device_buffer) {
 
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->nd != 1) return 0;
+  if (plan->pers_nb) return plan->pers_items;
   return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->d.groups;
 }
 
@@ -419,6 +476,13 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = (int)p.d.stride[0]; a.accumulate = p.accumulate;
     a.stamps = (unsigned long long*)p.debug_stamps;
+    if (p.pers_nb) {
+      fc::Conv1dPersArgs pa;
+      pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;
+      pa.debug_mode = getenv("FFTCONV_DEBUG_MODE") ? atoi(getenv("FFTCONV_DEBUG_MODE")) : 0;
+      FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
+      return FC_OK;
+    }
     const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;
     if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
     FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "conv1d_fused.hpp"
+#include "conv1d_pers.hpp"
 #include "nd_passes.hpp"
 #include "spectrum1d.hpp"
 
@@ -21,6 +22,11 @@ struct TileImpl {
   hipError_t (*rows_c2r)(const RowsC2RArgs& a, hipStream_t st);
   hipError_t (*fusedc)(int cib, const FusedCArgs& a, hipStream_t st);   // hipErrorInvalidValue if cib unsupported
   int fusedc_max_cib;
+  // persistent fused 1-D kernel (CIB = 8): nb = batch items per workgroup; returns hipErrorInvalidValue if not built
+  hipError_t (*conv1d_pers)(int nb, const Conv1dPersArgs& a, int grid, hipStream_t st);
+  int pers_nb[2];        // supported nb values (0 = none)
+  size_t pers_lds[2];    // LDS bytes for each
+  int pers_nt[2];
 };
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();

@@ -3,6 +3,8 @@
 // geometries compile in parallel.
 #include "fc_internal.h"
 
+#include <cstdlib>
+
 #ifndef FC_P
 #error "compile with -DFC_P=<points per thread> -DFC_S=<lane split> -DFC_NT=<threads of the fused 1-D kernel>"
 #endif
@@ -134,6 +136,39 @@ hipError_t fusedc_dispatch(int cib, const FusedCArgs& a, hipStream_t st) {
   }
 }
 
+// persistent kernel: only for geometries whose twiddle table + NB*4 sequences fit in LDS
+#if FC_P == 32 && FC_S == 2
+constexpr int kPersNb0 = 1, kPersNb1 = 2;
+#elif FC_P == 32 && FC_S == 1
+constexpr int kPersNb0 = 2, kPersNb1 = 4;
+#else
+constexpr int kPersNb0 = 0, kPersNb1 = 0;
+#endif
+constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_t)nb * 4 * GG::LSEQ) * sizeof(float2); }
+
+template <int NB, int DEPTH>
+hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
+  if constexpr (NB == 0) {
+    return hipErrorInvalidValue;
+  } else {
+    constexpr int NT = NB * 4 * GG::TS;
+    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, DEPTH>;
+    const size_t lds = pers_lds_bytes(NB);
+    static bool done = false;
+    hipError_t e = ensure_lds(k, lds, &done);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+    return hipGetLastError();
+  }
+}
+
+hipError_t pers_dispatch(int nb, const Conv1dPersArgs& a, int grid, hipStream_t st) {
+  static const int depth = getenv("FFTCONV_MIXDEPTH") ? atoi(getenv("FFTCONV_MIXDEPTH")) : 4;   // tuning knob
+  if (nb != 0 && nb == kPersNb0) return depth == 2 ? launch_pers<kPersNb0, 2>(a, grid, st) : launch_pers<kPersNb0, 4>(a, grid, st);
+  if (nb != 0 && nb == kPersNb1) return depth == 2 ? launch_pers<kPersNb1, 2>(a, grid, st) : launch_pers<kPersNb1, 4>(a, grid, st);
+  return hipErrorInvalidValue;
+}
+
 }  // namespace
 
 #define FC_CAT_(a, b, c, d) a##b##c##d
@@ -141,7 +176,10 @@ hipError_t fusedc_dispatch(int cib, const FusedCArgs& a, hipStream_t st) {
 const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
   static const TileImpl impl = {kT, FC_P, FC_S, FC_NT, GG::LSEQ, kLSEQP, kNSEQ_C, kNSEQ_R,
                                 conv1d_dispatch, spec1d_dispatch, rows_r2c_dispatch, c2c_dispatch<false>,
-                                c2c_dispatch<true>, rows_c2r_dispatch, fusedc_dispatch, kFusedMaxCib};
+                                c2c_dispatch<true>, rows_c2r_dispatch, fusedc_dispatch, kFusedMaxCib,
+                                pers_dispatch, {kPersNb0, kPersNb1},
+                                {kPersNb0 ? pers_lds_bytes(kPersNb0) : 0, kPersNb1 ? pers_lds_bytes(kPersNb1) : 0},
+                                {kPersNb0 * 4 * GG::TS, kPersNb1 * 4 * GG::TS}};
   return &impl;
 }
 

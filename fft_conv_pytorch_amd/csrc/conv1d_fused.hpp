@@ -39,6 +39,7 @@ struct Conv1dArgs {
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
+  int delay_from, delay_ticks; // experiment: workgroups >= delay_from start delay_ticks (10 ns units) late
 };
 
 // Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
 
+  if (a.delay_ticks > 0 && (int)blockIdx.x >= a.delay_from && (int)blockIdx.x < 2 * a.delay_from) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.delay_ticks) __builtin_amdgcn_s_sleep(8);
+  }
   stamp(a.stamps, 0);
   for (int ic = 0; ic < n_ichunks; ++ic) {
     // ------------------------------------------------ forward pass A (global -> regs -> LDS)
@@ -172,7 +177,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       // byte offsets inside the group's spectrum: uniform part in SGPRs, lane part = f*16
       const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;   // bytes between output channels
       const unsigned wbase = (unsigned)(oc * a.cob) * ostride + (unsigned)(ic * NPI) * (T / 2) * 16u;
-      constexpr int FB = (T / 2 >= 2 * NT) ? 2 : 1;   // bin pairs per thread per iteration
       // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
       // lane (output o, bin) of wave 0 owns one real output; its loads are issued here and consumed
       // after the main loop so their latency is hidden.
@@ -187,54 +191,72 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           sbz[p] = zin[p * G::LSEQ + G::nat(sb_f)];
         }
       }
-#pragma unroll 1
-      for (int fb = tid; fb < T / 2; fb += NT * FB) {
-        float xr[FB][CIB], xi[FB][CIB];
+      // Main bins: step = (bin pair of this thread, output pair q).  Two register sets alternate so
+      // the 2*NPI spectrum loads of the next step are in flight while this one is contracted.
+      constexpr int BPT = (T / 2 + NT - 1) / NT;          // bin pairs per thread
+      const int nsteps = BPT * npo;
+      float4 wA[2 * NPI], wB[2 * NPI];
+      float xr[CIB], xi[CIB];
+      auto issue = [&](int m, int q, float4 (&dst)[2 * NPI]) {
+        const unsigned vo = (unsigned)(tid + m * NT) * 16u;     // beyond T/2: out of the descriptor -> zeros
+        const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
 #pragma unroll
-        for (int u = 0; u < FB; ++u) {
-          const int f = fb + u * NT;
-          const int fm = (T - f) & (T - 1);           // f = 0 (thread 0) is redone harmlessly and skipped below
+        for (int p = 0; p < NPI; ++p) {
+          dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
+          dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
+        }
+      };
+      auto step = [&](int m, int q, const float4 (&wc)[2 * NPI]) {
+        const int f = tid + m * NT;
+        const bool live = f < T / 2 && f != 0;             // f = 0 belongs to the self-paired lanes
+        const int fc = live ? f : 1;
+        const int fm = T - fc;
+        if (q == 0) {
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
-            const float2 zf = zin[p * G::LSEQ + G::nat(f)];
+            const float2 zf = zin[p * G::LSEQ + G::nat(fc)];
             const float2 zg = zin[p * G::LSEQ + G::nat(fm)];
-            xr[u][2 * p] = zf.x + zg.x;      xi[u][2 * p] = zf.y - zg.y;        // 2*X_even[f]
-            xr[u][2 * p + 1] = zf.y + zg.y;  xi[u][2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
+            xr[2 * p] = zf.x + zg.x;      xi[2 * p] = zf.y - zg.y;        // 2*X_even[f]
+            xr[2 * p + 1] = zf.y + zg.y;  xi[2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
           }
         }
+        float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
 #pragma unroll
-        for (int q = 0; q < NPI; ++q) {
-          if (q < npo) {
-            const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-#pragma unroll
-            for (int u = 0; u < FB; ++u) {
-              const int f = fb + u * NT;
-              float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
-#pragma unroll
-              for (int p = 0; p < NPI; ++p) {
-                const float4 ha = buf_load_f32x4(wg, (unsigned)f * 16u, sa + p * (T / 2) * 16);
-                const float4 hb = buf_load_f32x4(wg, (unsigned)f * 16u, sb + p * (T / 2) * 16);
-                yar = fmaf(xr[u][2 * p], ha.x, yar); yar = fmaf(-xi[u][2 * p], ha.y, yar);
-                yai = fmaf(xr[u][2 * p], ha.y, yai); yai = fmaf(xi[u][2 * p], ha.x, yai);
-                yar = fmaf(xr[u][2 * p + 1], ha.z, yar); yar = fmaf(-xi[u][2 * p + 1], ha.w, yar);
-                yai = fmaf(xr[u][2 * p + 1], ha.w, yai); yai = fmaf(xi[u][2 * p + 1], ha.z, yai);
-                ybr = fmaf(xr[u][2 * p], hb.x, ybr); ybr = fmaf(-xi[u][2 * p], hb.y, ybr);
-                ybi = fmaf(xr[u][2 * p], hb.y, ybi); ybi = fmaf(xi[u][2 * p], hb.x, ybi);
-                ybr = fmaf(xr[u][2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[u][2 * p + 1], hb.w, ybr);
-                ybi = fmaf(xr[u][2 * p + 1], hb.w, ybi); ybi = fmaf(xi[u][2 * p + 1], hb.z, ybi);
-              }
-              if (f != 0) {
-                const int fm = T - f;
-                // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
-                float2 vf = make_float2(yar - ybi, yai + ybr);
-                float2 vg = make_float2(yar + ybi, ybr - yai);
-                float2* pf = vout + q * G::LSEQ + G::nat(f);
-                float2* pg = vout + q * G::LSEQ + G::nat(fm);
-                if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
-                *pf = vf; *pg = vg;
-              }
-            }
-          }
+        for (int p = 0; p < NPI; ++p) {
+          const float4 ha = wc[2 * p], hb = wc[2 * p + 1];
+          yar = fmaf(xr[2 * p], ha.x, yar); yar = fmaf(-xi[2 * p], ha.y, yar);
+          yai = fmaf(xr[2 * p], ha.y, yai); yai = fmaf(xi[2 * p], ha.x, yai);
+          yar = fmaf(xr[2 * p + 1], ha.z, yar); yar = fmaf(-xi[2 * p + 1], ha.w, yar);
+          yai = fmaf(xr[2 * p + 1], ha.w, yai); yai = fmaf(xi[2 * p + 1], ha.z, yai);
+          ybr = fmaf(xr[2 * p], hb.x, ybr); ybr = fmaf(-xi[2 * p], hb.y, ybr);
+          ybi = fmaf(xr[2 * p], hb.y, ybi); ybi = fmaf(xi[2 * p], hb.x, ybi);
+          ybr = fmaf(xr[2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[2 * p + 1], hb.w, ybr);
+          ybi = fmaf(xr[2 * p + 1], hb.w, ybi); ybi = fmaf(xi[2 * p + 1], hb.z, ybi);
+        }
+        if (live) {
+          // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
+          float2 vf = make_float2(yar - ybi, yai + ybr);
+          float2 vg = make_float2(yar + ybi, ybr - yai);
+          float2* pf = vout + q * G::LSEQ + G::nat(fc);
+          float2* pg = vout + q * G::LSEQ + G::nat(fm);
+          if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
+          *pf = vf; *pg = vg;
+        }
+      };
+      {
+        int m = 0, q = 0;                                   // position of the step being contracted
+        issue(0, 0, wA);
+#pragma unroll 1
+        for (int s2 = 0; s2 < nsteps; s2 += 2) {
+          int q1 = q + 1, m1 = m;
+          if (q1 == npo) { q1 = 0; ++m1; }
+          int q2 = q1 + 1, m2 = m1;
+          if (q2 == npo) { q2 = 0; ++m2; }
+          if (s2 + 1 < nsteps) issue(m1, q1, wB);
+          step(m, q, wA);
+          if (s2 + 2 < nsteps) issue(m2, q2, wA);
+          if (s2 + 1 < nsteps) step(m1, q1, wB);
+          m = m2; q = q2;
         }
       }
       if (sb_act) {

@@ -26,11 +26,11 @@ enum PadMode : int { PAD_CONSTANT = 0, PAD_REFLECT = 1, PAD_REPLICATE = 2, PAD_C
 
 struct Conv1dArgs {
   const float* x;        // (B, Cin, L)
-  const float4* wspec;   // [G][Cog_pad][Cig_pad/2][T/2] float4 = {H(o,2ip)[f], H(o,2ip+1)[f]}
+  const f4* wspec;       // [G][Cog_pad][Cig_pad/2][T/2] float4 = {H(o,2ip)[f], H(o,2ip+1)[f]}
   const float* bias;     // (Cout) or null
   float* y;              // (B, Cout, Lout)
-  const float2* twA;     // [P][N2]
-  const float2* twB;     // [S][P]
+  const f2* twA;         // [P][N2]
+  const f2* twB;         // [S][P] (unused: the lane-split twiddles are compile-time constants)
   int B, Cin, Cout, G, Cig, Cog;
   int Cig_pad, Cog_pad;  // padded to CIB / COB multiples (spectrum layout)
   int cob;               // out channels per chunk (even)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   constexpr int NPI = CIB / 2;
   constexpr int SEQ_PER_IT = NT / G::TS;  // sequences processed concurrently
   static_assert(NPI <= SEQ_PER_IT, "one sequence per thread per pass");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
 
   // ---- unit decode: id = ((b*ntiles + tile)*n_ochunks + oc)*G + g  (g fastest: a
   // group's spectrum stays on one XCD's L2 when G is a multiple of 8)
@@ -95,8 +95,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const int seq0 = tid / G::TS;
   const int tseq = tid % G::TS;
   const int npo = a.cob / 2;
-  float2* zin = lds;
-  float2* vout = a.accumulate ? lds + NPI * G::LSEQ : lds;
+  f2* zin = lds;
+  f2* vout = a.accumulate ? lds + NPI * G::LSEQ : lds;
 
   const int n_ichunks = a.Cig_pad / CIB;
   const int tile_pos = tile * a.V - a.pad;     // signal coordinate of tile sample 0
@@ -104,7 +104,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   // buffer descriptors from uniform values only (no waterfall loops)
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const BufRsrc xg = make_rsrc(a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L, (unsigned)a.Cig * (unsigned)a.L * 4u);
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
     if (seq0 < NPI) {
       const int sq = seq0;
       const int ci0 = ic * CIB + 2 * sq;         // channel within the group
-      float re[P], im[P];
+      f2 v[P];
       const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;
       const float* r0 = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig + ci0) * a.L;
       const float* r1 = r0 + a.L;
@@ -128,29 +127,25 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         const unsigned v1 = v0 + (unsigned)a.L * 4u;
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
-          re[n1] = buf_load_f32(xg, v0, G::N2 * n1 * 4);
-          im[n1] = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+          v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+          v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
         }
       } else {
         // border tile / odd channel count: a rolled loop stages this thread's own
         // column in LDS (no long-lived masks, no register-array indexing), then the
         // column is read back -- same thread, same addresses, so no barrier.
-        float2* col = zin + sq * G::LSEQ + tseq;
+        f2* col = zin + sq * G::LSEQ + tseq;
 #pragma unroll 1
         for (int n1 = 0; n1 < P; ++n1) {
           const int pos = tile_pos + G::N2 * n1 + tseq;
-          col[n1 * G::RS] = make_float2(load_padded(r0, pos, a.L, a.pad, pm, has0),
-                                        load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1));
+          col[n1 * G::RS] = mk2(load_padded(r0, pos, a.L, a.pad, pm, has0),
+                                load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1));
         }
 #pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
-          const float2 v = col[n1 * G::RS];
-          re[n1] = v.x; im[n1] = v.y;
-        }
+        for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
       }
       if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(a.stamps, 1); }
-      fft_regs<P, -1>(re, im);
-      passA_twiddle_store<G, -1>(re, im, zin + sq * G::LSEQ, tseq, twA);
+      passA_fft_twiddle_store<G, -1>(v, zin + sq * G::LSEQ, tseq, twA);
     }
     stamp(a.stamps, 2);
     __syncthreads();
@@ -158,15 +153,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
     // ------------------------------------------------ forward pass B (LDS -> regs -> LDS natural)
     {
       // every row is read before anyone writes: the two layouts alias
-      float re[P], im[P];
-      if (seq0 < NPI) passB_load<G>(re, im, zin + seq0 * G::LSEQ, tseq);
+      f2 v[P];
+      if (seq0 < NPI) passB_load<G>(v, zin + seq0 * G::LSEQ, tseq);
       __syncthreads();
       if (seq0 < NPI) {
-        const int j = passB_compute<G, -1>(re, im, tseq, twB);
+        const int j = passB_compute<G, -1>(v, tseq);
         const int k1 = tseq >> G::LGS;
-        float2* dst = zin + seq0 * G::LSEQ + G::nat(k1 + P * P * j);   // nat() pad is constant per j block
+        f2* dst = zin + seq0 * G::LSEQ + G::nat(k1 + P * P * j);   // nat() pad is constant per j block
 #pragma unroll
-        for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+        for (int k = 0; k < P; ++k) dst[P * k] = v[k];
       }
     }
     stamp(a.stamps, 4);
@@ -182,8 +177,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       // after the main loop so their latency is hidden.
       const int sb_o = tid >> 1, sb_f = (tid & 1) ? T / 2 : 0;
       const bool sb_act = tid < 2 * a.cob;
-      float4 sbw[NPI];
-      float2 sbz[NPI];
+      f4 sbw[NPI];
+      f2 sbz[NPI];
       if (sb_act) {
 #pragma unroll
         for (int p = 0; p < NPI; ++p) {
@@ -195,9 +190,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       // the 2*NPI spectrum loads of the next step are in flight while this one is contracted.
       constexpr int BPT = (T / 2 + NT - 1) / NT;          // bin pairs per thread
       const int nsteps = BPT * npo;
-      float4 wA[2 * NPI], wB[2 * NPI];
-      float xr[CIB], xi[CIB];
-      auto issue = [&](int m, int q, float4 (&dst)[2 * NPI]) {
+      f4 wA[2 * NPI], wB[2 * NPI];
+      f2 xe[NPI], xo[NPI];                                  // 2*X of the even / odd channel of every pair
+      auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
         const unsigned vo = (unsigned)(tid + m * NT) * 16u;     // beyond T/2: out of the descriptor -> zeros
         const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
 #pragma unroll
@@ -206,7 +201,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
         }
       };
-      auto step = [&](int m, int q, const float4 (&wc)[2 * NPI]) {
+      auto step = [&](int m, int q, const f4 (&wc)[2 * NPI]) {
         const int f = tid + m * NT;
         const bool live = f < T / 2 && f != 0;             // f = 0 belongs to the self-paired lanes
         const int fc = live ? f : 1;
@@ -214,32 +209,26 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         if (q == 0) {
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
-            const float2 zf = zin[p * G::LSEQ + G::nat(fc)];
-            const float2 zg = zin[p * G::LSEQ + G::nat(fm)];
-            xr[2 * p] = zf.x + zg.x;      xi[2 * p] = zf.y - zg.y;        // 2*X_even[f]
-            xr[2 * p + 1] = zf.y + zg.y;  xi[2 * p + 1] = zg.x - zf.x;    // 2*X_odd[f]
+            const f2 zf = zin[p * G::LSEQ + G::nat(fc)];
+            const f2 zg = zin[p * G::LSEQ + G::nat(fm)];
+            xe[p] = add_conj(zf, zg);          // 2*X_even[f] = Z[f] + conj(Z[T-f])
+            xo[p] = sub_conj_divi(zf, zg);     // 2*X_odd[f]  = (Z[f] - conj(Z[T-f])) / i
           }
         }
-        float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
+        f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < NPI; ++p) {
-          const float4 ha = wc[2 * p], hb = wc[2 * p + 1];
-          yar = fmaf(xr[2 * p], ha.x, yar); yar = fmaf(-xi[2 * p], ha.y, yar);
-          yai = fmaf(xr[2 * p], ha.y, yai); yai = fmaf(xi[2 * p], ha.x, yai);
-          yar = fmaf(xr[2 * p + 1], ha.z, yar); yar = fmaf(-xi[2 * p + 1], ha.w, yar);
-          yai = fmaf(xr[2 * p + 1], ha.w, yai); yai = fmaf(xi[2 * p + 1], ha.z, yai);
-          ybr = fmaf(xr[2 * p], hb.x, ybr); ybr = fmaf(-xi[2 * p], hb.y, ybr);
-          ybi = fmaf(xr[2 * p], hb.y, ybi); ybi = fmaf(xi[2 * p], hb.x, ybi);
-          ybr = fmaf(xr[2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[2 * p + 1], hb.w, ybr);
-          ybi = fmaf(xr[2 * p + 1], hb.w, ybi); ybi = fmaf(xi[2 * p + 1], hb.z, ybi);
+          const f4 ha = wc[2 * p], hb = wc[2 * p + 1];
+          cmac(ya, xe[p], ha.xy); cmac(ya, xo[p], ha.zw);
+          cmac(yb, xe[p], hb.xy); cmac(yb, xo[p], hb.zw);
         }
         if (live) {
           // V[f] = Ya + i*Yb ; V[T-f] = conj(Ya) + i*conj(Yb)
-          float2 vf = make_float2(yar - ybi, yai + ybr);
-          float2 vg = make_float2(yar + ybi, ybr - yai);
-          float2* pf = vout + q * G::LSEQ + G::nat(fc);
-          float2* pg = vout + q * G::LSEQ + G::nat(fm);
-          if (ic != 0) { const float2 of = *pf, og = *pg; vf.x += of.x; vf.y += of.y; vg.x += og.x; vg.y += og.y; }
+          f2 vf = add_pi(ya, yb);
+          f2 vg = conj_add_iconj(ya, yb);
+          f2* pf = vout + q * G::LSEQ + G::nat(fc);
+          f2* pg = vout + q * G::LSEQ + G::nat(fm);
+          if (ic != 0) { vf += *pf; vg += *pg; }
           *pf = vf; *pg = vg;
         }
       };
@@ -278,20 +267,16 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
 
   // -------------------------------------------------- inverse pass A' (LDS natural -> regs -> LDS rows)
   {
-    float re[P], im[P];
+    f2 v[P];
     const bool act = seq0 < npo;
     if (act) {
-      const float2* src = vout + seq0 * G::LSEQ;
+      const f2* src = vout + seq0 * G::LSEQ;
 #pragma unroll
-      for (int i1 = 0; i1 < P; ++i1) {
-        const float2 v = src[G::nat(G::N2 * i1 + tseq)];
-        re[i1] = v.x; im[i1] = v.y;
-      }
+      for (int i1 = 0; i1 < P; ++i1) v[i1] = src[G::nat(G::N2 * i1 + tseq)];
     }
     __syncthreads();
     if (act) {
-      fft_regs<P, +1>(re, im);
-      passA_twiddle_store<G, +1>(re, im, vout + seq0 * G::LSEQ, tseq, twA);
+      passA_fft_twiddle_store<G, +1>(v, vout + seq0 * G::LSEQ, tseq, twA);
     }
   }
   stamp(a.stamps, 8);
@@ -300,9 +285,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   // -------------------------------------------------- inverse pass B' (LDS -> regs -> HBM)
   if (seq0 < npo) {
     const int sq = seq0;
-    float re[P], im[P];
-    passB_load<G>(re, im, vout + sq * G::LSEQ, tseq);
-    const int j = passB_compute<G, +1>(re, im, tseq, twB);
+    f2 v[P];
+    passB_load<G>(v, vout + sq * G::LSEQ, tseq);
+    const int j = passB_compute<G, +1>(v, tseq);
     const int o1 = tseq >> G::LGS;
     const int co0 = oc * a.cob + 2 * sq;           // out channel within the group
     const bool has0 = co0 < a.Cog, has1 = co0 + 1 < a.Cog;
@@ -318,11 +303,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       if (has1) {
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          if (nbase + P * k < limit) { y0[P * k] = re[k] + bias0; y1[P * k] = im[k] + bias1; }
+          if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
       } else if (has0) {
 #pragma unroll
         for (int k = 0; k < P; ++k)
-          if (nbase + P * k < limit) y0[P * k] = re[k] + bias0;
+          if (nbase + P * k < limit) y0[P * k] = v[k].x + bias0;
       }
     } else {
       float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout;
@@ -333,8 +318,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         const int t = t0 + n;
         const int idx = t / a.stride;
         if (n < limit && idx * a.stride == t) {
-          if (has0) y0[idx] = re[k] + bias0;
-          if (has1) y1[idx] = im[k] + bias1;
+          if (has0) y0[idx] = v[k].x + bias0;
+          if (has1) y1[idx] = v[k].y + bias1;
         }
       }
     }

@@ -26,19 +26,6 @@ struct Conv1dPersArgs {
   int debug_mode;   // experiments: 1 = mix without spectrum loads, 2 = mix without contraction, 3 = no LDS traffic in mix
 };
 
-template <class G, int DIR>
-__device__ __forceinline__ void passA_twiddle_store_lds(float (&re)[G::P], float (&im)[G::P], float2* __restrict__ lseq,
-                                                        int n2, const float2* __restrict__ twl) {
-  lseq[n2] = make_float2(re[0], im[0]);
-#pragma unroll
-  for (int k1 = 1; k1 < G::P; ++k1) {
-    const float2 w = twl[k1 * G::N2 + n2];
-    const float c = w.x, s = (DIR > 0) ? -w.y : w.y;
-    const float xr = re[k1], xi = im[k1];
-    lseq[k1 * G::RS + n2] = make_float2(fmaf(c, xr, -s * xi), fmaf(c, xi, s * xr));
-  }
-}
-
 __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, int slot) {
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
@@ -53,7 +40,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   static_assert((T / 2) % NT == 0, "bin pairs divide evenly over the threads");
   constexpr int BP = (T / 2) / NT;          // bin pairs per thread
   constexpr int TWN = P * G::N2;            // pass-A twiddle table entries
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const Conv1dArgs& a = pa.c;
 
   const int tid = threadIdx.x;
@@ -61,12 +48,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const int tseq = tid % G::TS;
   const int nb = sq / NPI, pr = sq % NPI;
   constexpr int npo = NPI;                  // full output chunks only
-  float2* twl = lds;
-  float2* zbuf = lds + TWN;                 // [NSEQ][LSEQ]
-  float2* zseq = zbuf + sq * G::LSEQ;
+  f2* twl = lds;
+  f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ]
+  f2* zseq = zbuf + sq * G::LSEQ;
 
   for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   __syncthreads();
@@ -90,7 +76,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
     // ------------------------------------------------ forward pass A
     {
-      float re[P], im[P];
+      f2 v[P];
       const int ci0 = 2 * pr;
       const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
       if (interior && has1) {
@@ -98,29 +84,25 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         const unsigned v1 = v0 + (unsigned)a.L * 4u;
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
-          re[n1] = buf_load_f32(xg, v0, G::N2 * n1 * 4);
-          im[n1] = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+          v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+          v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
         }
       } else {
         const float* r0 = xbase + ((size_t)(act_in ? nb : 0) * a.Cin + (has0 ? ci0 : 0)) * a.L;
         const float* r1 = has1 ? r0 + a.L : r0;
-        float2* col = zseq + tseq;
+        f2* col = zseq + tseq;
 #pragma unroll 1
         for (int n1 = 0; n1 < P; ++n1) {
           const int pos = tile_pos + G::N2 * n1 + tseq;
-          col[n1 * G::RS] = make_float2(load_padded(r0, pos, a.L, a.pad, pm, has0),
-                                        load_padded(r1, pos, a.L, a.pad, pm, has1));
+          col[n1 * G::RS] = mk2(load_padded(r0, pos, a.L, a.pad, pm, has0), load_padded(r1, pos, a.L, a.pad, pm, has1));
         }
 #pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
-          const float2 v = col[n1 * G::RS];
-          re[n1] = v.x; im[n1] = v.y;
-        }
+        for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
       }
       if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
       if (act_in) {
-        fft_regs<P, -1>(re, im);
-        passA_twiddle_store_lds<G, -1>(re, im, zseq, tseq, twl);
+        fft_regs<P, -1>(v);
+        passA_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
       }
     }
     stamp_item(a.stamps, it, 2);
@@ -128,15 +110,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     stamp_item(a.stamps, it, 3);
     // ------------------------------------------------ forward pass B
     {
-      float re[P], im[P];
-      if (act_in) passB_load<G>(re, im, zseq, tseq);
+      f2 v[P];
+      if (act_in) passB_load<G>(v, zseq, tseq);
       __syncthreads();
       if (act_in) {
-        const int j = passB_compute<G, -1>(re, im, tseq, twB);
+        const int j = passB_compute<G, -1>(v, tseq);
         const int k1 = tseq >> G::LGS;
-        float2* dst = zseq + G::nat(k1 + P * P * j);
+        f2* dst = zseq + G::nat(k1 + P * P * j);
 #pragma unroll
-        for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+        for (int k = 0; k < P; ++k) dst[P * k] = v[k];
       }
     }
     stamp_item(a.stamps, it, 4);
@@ -152,8 +134,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       static_assert(NB * CIB * 2 <= 64, "the self-paired bins are handled by one wave");
       const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
       const bool sb_act = tid < NB * CIB * 2 && sb_b < wi.nbc;
-      float4 sbw[NPI];
-      float2 sbz[NPI];
+      f4 sbw[NPI];
+      f2 sbz[NPI];
       if (sb_act) {
 #pragma unroll
         for (int p = 0; p < NPI; ++p) {
@@ -163,12 +145,12 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       }
       // spectrum pipeline: step = (bin pair m, output pair q); the 2*NPI float4 of the next step are
       // requested before the current step is contracted (two named register sets, static indices)
-      auto issue = [&](int m, int q, float4 (&dst)[2 * NPI]) {
+      auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
         const unsigned vo = (unsigned)(tid + m * NT) * 16u;
         const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
         if (pa.debug_mode == 1) {
 #pragma unroll
-          for (int p = 0; p < 2 * NPI; ++p) dst[p] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+          for (int p = 0; p < 2 * NPI; ++p) { dst[p].x = 1.f; dst[p].y = 0.5f; dst[p].z = 0.25f; dst[p].w = 2.f; }
           return;
         }
 #pragma unroll
@@ -177,8 +159,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
         }
       };
-      float xr[NB][CIB], xi[NB][CIB];
-      auto contract = [&](int f, int fm, int q, const float4 (&wc)[2 * NPI]) {
+      f2 xe[NB][NPI], xo[NB][NPI];       // 2*X of the even / odd channel of every pair
+      auto contract = [&](int f, int fm, int q, const f4 (&wc)[2 * NPI]) {
         if (pa.debug_mode == 2) {
 #pragma unroll
           for (int p = 0; p < 2 * NPI; ++p) asm volatile("" :: "v"(wc[p].x), "v"(wc[p].y), "v"(wc[p].z), "v"(wc[p].w));
@@ -187,23 +169,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         if (q < npo) {
 #pragma unroll
           for (int b = 0; b < NB; ++b) {
-            float yar = 0.f, yai = 0.f, ybr = 0.f, ybi = 0.f;
+            f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
 #pragma unroll
             for (int p = 0; p < NPI; ++p) {
-              const float4 ha = wc[2 * p], hb = wc[2 * p + 1];
-              yar = fmaf(xr[b][2 * p], ha.x, yar); yar = fmaf(-xi[b][2 * p], ha.y, yar);
-              yai = fmaf(xr[b][2 * p], ha.y, yai); yai = fmaf(xi[b][2 * p], ha.x, yai);
-              yar = fmaf(xr[b][2 * p + 1], ha.z, yar); yar = fmaf(-xi[b][2 * p + 1], ha.w, yar);
-              yai = fmaf(xr[b][2 * p + 1], ha.w, yai); yai = fmaf(xi[b][2 * p + 1], ha.z, yai);
-              ybr = fmaf(xr[b][2 * p], hb.x, ybr); ybr = fmaf(-xi[b][2 * p], hb.y, ybr);
-              ybi = fmaf(xr[b][2 * p], hb.y, ybi); ybi = fmaf(xi[b][2 * p], hb.x, ybi);
-              ybr = fmaf(xr[b][2 * p + 1], hb.z, ybr); ybr = fmaf(-xi[b][2 * p + 1], hb.w, ybr);
-              ybi = fmaf(xr[b][2 * p + 1], hb.w, ybi); ybi = fmaf(xi[b][2 * p + 1], hb.z, ybi);
+              const f4 ha = wc[2 * p], hb = wc[2 * p + 1];
+              cmac(ya, xe[b][p], ha.xy); cmac(ya, xo[b][p], ha.zw);
+              cmac(yb, xe[b][p], hb.xy); cmac(yb, xo[b][p], hb.zw);
             }
             if (f != 0 && b < wi.nbc) {
-              float2* zb = zbuf + (b * NPI + q) * G::LSEQ;
-              zb[G::nat(f)] = make_float2(yar - ybi, yai + ybr);
-              zb[G::nat(fm)] = make_float2(yar + ybi, ybr - yai);
+              f2* zb = zbuf + (b * NPI + q) * G::LSEQ;
+              zb[G::nat(f)] = add_pi(ya, yb);
+              zb[G::nat(fm)] = conj_add_iconj(ya, yb);
             }
           }
         }
@@ -217,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       // VGPRs hipcc spills them and the mix gets slower; the mix is bound by the ~70 GB/s per-CU
       // L2 -> L1 rate, not by latency.)  Workgroups start their walk at different bin pairs.
       static_assert(NPI % 2 == 0, "pipeline alternates two register sets");
-      float4 wA[2 * NPI], wB[2 * NPI];
+      f4 wA[2 * NPI], wB[2 * NPI];
       const int m0 = (int)(blockIdx.x % BP);
       auto mrot = [&](int m) { const int r = m + m0; return r >= BP ? r - BP : r; };
       issue(mrot(0), 0, wA);
@@ -228,13 +204,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         const int fm = (T - f) & (T - 1);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-          const float2* zb = zbuf + b * NPI * G::LSEQ;
+          const f2* zb = zbuf + b * NPI * G::LSEQ;
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
-            const float2 zf = zb[p * G::LSEQ + G::nat(f)];
-            const float2 zg = zb[p * G::LSEQ + G::nat(fm)];
-            xr[b][2 * p] = zf.x + zg.x;      xi[b][2 * p] = zf.y - zg.y;
-            xr[b][2 * p + 1] = zf.y + zg.y;  xi[b][2 * p + 1] = zg.x - zf.x;
+            const f2 zf = zb[p * G::LSEQ + G::nat(f)];
+            const f2 zg = zb[p * G::LSEQ + G::nat(fm)];
+            xe[b][p] = add_conj(zf, zg);
+            xo[b][p] = sub_conj_divi(zf, zg);
           }
         }
 #pragma unroll
@@ -263,18 +239,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     // ------------------------------------------------ inverse pass A'
     const bool act_out = act_in && pr < npo;
     {
-      float re[P], im[P];
+      f2 v[P];
       if (act_out) {
 #pragma unroll
-        for (int i1 = 0; i1 < P; ++i1) {
-          const float2 v = zseq[G::nat(G::N2 * i1 + tseq)];
-          re[i1] = v.x; im[i1] = v.y;
-        }
+        for (int i1 = 0; i1 < P; ++i1) v[i1] = zseq[G::nat(G::N2 * i1 + tseq)];
       }
       __syncthreads();
       if (act_out) {
-        fft_regs<P, +1>(re, im);
-        passA_twiddle_store_lds<G, +1>(re, im, zseq, tseq, twl);
+        fft_regs<P, +1>(v);
+        passA_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
       }
     }
     stamp_item(a.stamps, it, 8);
@@ -282,9 +255,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     stamp_item(a.stamps, it, 9);
     // ------------------------------------------------ inverse pass B' + store
     if (act_out) {
-      float re[P], im[P];
-      passB_load<G>(re, im, zseq, tseq);
-      const int j = passB_compute<G, +1>(re, im, tseq, twB);
+      f2 v[P];
+      passB_load<G>(v, zseq, tseq);
+      const int j = passB_compute<G, +1>(v, tseq);
       const int o1 = tseq >> G::LGS;
       const int t0 = tile * a.V;
       const int limit = min(a.V, a.Lfull - t0);
@@ -293,7 +266,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       float* y1 = y0 + a.Lout;
 #pragma unroll
       for (int k = 0; k < P; ++k)
-        if (nbase + P * k < limit) { y0[P * k] = re[k] + bias0; y1[P * k] = im[k] + bias1; }
+        if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
     }
     stamp_item(a.stamps, it, 10);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }

@@ -56,8 +56,8 @@ const fc::TileImpl* find_tile(int T) {
 
 // Device twiddle tables, shared by every plan of the same tile geometry and device.
 struct Twiddles {
-  float2* twA = nullptr;  // [P][N2]  exp(-2 pi i n2 k1 / T)
-  float2* twB = nullptr;  // [S][P]   exp(-2 pi i r k / N2)
+  fc::f2* twA = nullptr;  // [P][N2]  exp(-2 pi i n2 k1 / T)
+  fc::f2* twB = nullptr;  // [S][P]   exp(-2 pi i r k / N2)
 };
 std::mutex g_tw_mutex;
 std::map<std::pair<int, int>, Twiddles> g_tw;  // (device, T)
@@ -70,23 +70,23 @@ int get_twiddles(const fc::TileImpl* t, Twiddles* out) {
   auto it = g_tw.find(key);
   if (it != g_tw.end()) { *out = it->second; return FC_OK; }
   const int P = t->P, S = t->S, N2 = P * S, T = t->T;
-  std::vector<float2> a((size_t)P * N2), b((size_t)S * P);
+  std::vector<fc::f2> a((size_t)P * N2), b((size_t)S * P);
   const double tau = 6.283185307179586476925286766559;
   for (int k1 = 0; k1 < P; ++k1)
     for (int n2 = 0; n2 < N2; ++n2) {
       const double ang = -tau * (double)((long long)k1 * n2 % T) / (double)T;
-      a[(size_t)k1 * N2 + n2] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      a[(size_t)k1 * N2 + n2] = fc::f2{(float)std::cos(ang), (float)std::sin(ang)};
     }
   for (int r = 0; r < S; ++r)
     for (int k = 0; k < P; ++k) {
       const double ang = -tau * (double)(r * k) / (double)N2;
-      b[(size_t)r * P + k] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      b[(size_t)r * P + k] = fc::f2{(float)std::cos(ang), (float)std::sin(ang)};
     }
   Twiddles tw;
-  FC_HIP(hipMalloc(&tw.twA, a.size() * sizeof(float2)));
-  FC_HIP(hipMalloc(&tw.twB, b.size() * sizeof(float2)));
-  FC_HIP(hipMemcpy(tw.twA, a.data(), a.size() * sizeof(float2), hipMemcpyHostToDevice));
-  FC_HIP(hipMemcpy(tw.twB, b.data(), b.size() * sizeof(float2), hipMemcpyHostToDevice));
+  FC_HIP(hipMalloc(&tw.twA, a.size() * sizeof(fc::f2)));
+  FC_HIP(hipMalloc(&tw.twB, b.size() * sizeof(fc::f2)));
+  FC_HIP(hipMemcpy(tw.twA, a.data(), a.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
+  FC_HIP(hipMemcpy(tw.twB, b.data(), b.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
   g_tw[key] = tw;
   *out = tw;
   return FC_OK;
@@ -117,7 +117,7 @@ struct fc_plan {
   int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
   int Fx;                     // Tx/2 + 1
   int nd_cob, nd_Cog_pad;
-  size_t ws_a, ws_b;          // float2 counts of the two workspace regions
+  size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
   int pers_grid, pers_items;
@@ -150,7 +150,7 @@ static int plan_1d(fc_plan* p) {
     const fc::TileImpl* t = tiles[i];
     if (d.tile_hint && t->T != d.tile_hint) continue;
     if (t->T < Kd) continue;
-    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(float2);
+    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
     if (lds > lds_cap) continue;
     if (t->NT / (t->P * t->S) < NPI) continue;
     const int64_t V = t->T - Kd + 1;
@@ -168,9 +168,9 @@ static int plan_1d(fc_plan* p) {
   p->tile = best;
   p->V = (int)(best->T - Kd + 1);
   p->ntiles = (int)((Lfull + p->V - 1) / p->V);
-  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * NPI * best->lseq * sizeof(float2);
-  p->lds_spec = (size_t)(best->NT / (best->P * best->S)) * best->lseq * sizeof(float2);
-  const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(float4);
+  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * NPI * best->lseq * sizeof(fc::f2);
+  p->lds_spec = (size_t)(best->NT / (best->P * best->S)) * best->lseq * sizeof(fc::f2);
+  const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(fc::f4);
   if (per_group >= ((size_t)1 << 32))
     return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
   p->spectrum_bytes = per_group * (size_t)d.groups;
@@ -263,7 +263,7 @@ static int plan_nd(fc_plan* p) {
     const fc::TileImpl* t = tiles[i];
     if (d.tile_hint && t->T != d.tile_hint) continue;
     if (t->T < Kd || p->CB > t->fusedc_max_cib) continue;
-    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * p->CB * t->lseqp * sizeof(float2);
+    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * p->CB * t->lseqp * sizeof(fc::f2);
     if (lds > lds_cap) continue;
     const int64_t V = t->T - Kd + 1;
     const int64_t nt = (Lfull + V - 1) / V;
@@ -280,7 +280,7 @@ static int plan_nd(fc_plan* p) {
   p->V = (int)(best->T - Kd + 1);
   p->ntiles = (int)((Lfull + p->V - 1) / p->V);
   p->Lfull = (int)Lfull;
-  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * p->CB * best->lseqp * sizeof(float2);
+  p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * p->CB * best->lseqp * sizeof(fc::f2);
 
   const size_t B = (size_t)d.batch, Ci = (size_t)d.in_channels, Co = (size_t)d.out_channels;
   const size_t Fx = (size_t)p->Fx;
@@ -303,8 +303,8 @@ static int plan_nd(fc_plan* p) {
   }
   p->ws_a = std::max(a_sig, a_w);
   p->ws_b = std::max(b_sig, b_w);
-  p->workspace_bytes = (p->ws_a + p->ws_b) * sizeof(float2);
-  p->spectrum_bytes = (size_t)d.groups * p->nd_Cog_pad * (p->Cig_pad / 2) * ncol * best->T * sizeof(float4);
+  p->workspace_bytes = (p->ws_a + p->ws_b) * sizeof(fc::f2);
+  p->spectrum_bytes = (size_t)d.groups * p->nd_Cog_pad * (p->Cig_pad / 2) * ncol * best->T * sizeof(fc::f4);
   int rc = get_twiddles(best, &p->tw);
   if (rc == FC_OK) rc = get_twiddles(p->tx, &p->twx);
   if (rc == FC_OK && p->tm) rc = get_twiddles(p->tm, &p->twm);
@@ -406,7 +406,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   if (p.nd == 1) {
     fc::Spec1dArgs a;
     a.w = weight;
-    a.wspec = (float4*)w_hat;
+    a.wspec = (fc::f4*)w_hat;
     a.twA = p.tw.twA;
     a.twB = p.tw.twB;
     a.G = (int)p.d.groups; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
@@ -419,8 +419,8 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   }
   // ---- 2-D / 3-D: the separable passes, fed from the dilated taps
   if (p.workspace_bytes && !workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
-  float2* wsA = (float2*)workspace;
-  float2* wsB = wsA + p.ws_a;
+  fc::f2* wsA = (fc::f2*)workspace;
+  fc::f2* wsB = wsA + p.ws_a;
   const int nd = p.nd;
   const int Co = (int)p.d.out_channels;
   FC_HIP(hipMemsetAsync(w_hat, 0, p.spectrum_bytes, st));    // phantom channels stay zero
@@ -438,7 +438,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   c.NV = 0; c.stride = 1;
   if (nd == 2) {
     // S1w[(o,i)][fx][y<Kd] -> wspec[..][fx][fy]
-    c.src = wsA; c.dst = (float2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
+    c.src = wsA; c.dst = (fc::f2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
     c.NA = Co * p.Cig; c.NC = 1; c.NB = p.Fx; c.NLEN = (int)p.kd[0];
     c.sa = (long long)p.Fx * r.NYa; c.sc = 0; c.sb = r.NYa; c.store_mode = 1;
     FC_HIP(p.tile->c2c_fwd(c, st));
@@ -451,7 +451,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     c.ta = (long long)p.Fx * Ty * Kz; c.tc = (long long)Ty * Kz; c.tf = Kz; c.store_mode = 0;
     FC_HIP(p.tm->c2c_fwd(c, st));
     // S2w[(o,i)][(fx,fy)][z<Kdz] -> wspec[..][(fx,fy)][fz]
-    c.src = wsB; c.dst = (float2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
+    c.src = wsB; c.dst = (fc::f2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
     c.NC = 1; c.NB = p.Fx * Ty; c.NLEN = Kz;
     c.sa = (long long)p.Fx * Ty * Kz; c.sc = 0; c.sb = Kz; c.store_mode = 1;
     FC_HIP(p.tile->c2c_fwd(c, st));
@@ -468,7 +468,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   if (p.d.has_bias && !bias) return fail(FC_ERR_INVALID, "plan was created with has_bias=1 but bias is NULL");
   if (p.nd == 1) {
     fc::Conv1dArgs a;
-    a.x = x; a.wspec = (const float4*)w_hat; a.bias = p.d.has_bias ? bias : nullptr; a.y = y;
+    a.x = x; a.wspec = (const fc::f4*)w_hat; a.bias = p.d.has_bias ? bias : nullptr; a.y = y;
     a.twA = p.tw.twA; a.twB = p.tw.twB;
     a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
@@ -492,8 +492,8 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   }
   // ---- 2-D / 3-D
   if (p.workspace_bytes && !workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
-  float2* wsA = (float2*)workspace;
-  float2* wsB = wsA + p.ws_a;
+  fc::f2* wsA = (fc::f2*)workspace;
+  fc::f2* wsB = wsA + p.ws_a;
   const int nd = p.nd;
   const int B = (int)p.d.batch, Ci = (int)p.d.in_channels, Co = (int)p.d.out_channels;
   auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = (int)p.d.padding[ax]; m.mode = p.d.padding_mode; return m; };
@@ -506,7 +506,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   FC_HIP(p.tx->rows_r2c(r, st));
 
   fc::FusedCArgs f{};
-  f.wspec = (const float4*)w_hat; f.twA = p.tw.twA; f.twB = p.tw.twB;
+  f.wspec = (const fc::f4*)w_hat; f.twA = p.tw.twA; f.twB = p.tw.twB;
   f.B = B; f.Cin = Ci; f.Cout = Co; f.G = (int)p.d.groups; f.Cig = p.Cig; f.Cog = p.Cog;
   f.Cig_pad = p.Cig_pad; f.Cog_pad = p.nd_Cog_pad; f.cob = p.nd_cob; f.n_ochunks = p.nd_Cog_pad / p.nd_cob;
   f.Kd = (int)p.kd[0]; f.V = p.V; f.ntiles = p.ntiles; f.Lfull = p.Lfull; f.NVo = (int)p.out_sp[0];

@@ -21,6 +21,59 @@
 
 namespace fc {
 
+// One complex value = one 64-bit VGPR pair.  gfx950 issues a wave64 VALU instruction in 4 cycles
+// whether it is v_fma_f32 or v_pk_fma_f32, so all complex arithmetic is written on packed
+// (re, im) pairs: a twiddle butterfly is 3 v_pk_fma_f32, a complex MAC is 2.  Where hipcc does not
+// fold the half-swaps / sign flips into op_sel / neg modifiers by itself, small asm helpers do.
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+// a + (-i)*b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ f2 add_mi(f2 a, f2 b) {
+  f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// a + (+i)*b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ f2 add_pi(f2 a, f2 b) {
+  f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// a + conj(b) = (a.x + b.x, a.y - b.y)
+__device__ __forceinline__ f2 add_conj(f2 a, f2 b) {
+  f2 d; asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// (a - conj(b)) / i = (a.y + b.y, b.x - a.x)
+__device__ __forceinline__ f2 sub_conj_divi(f2 a, f2 b) {
+  f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// conj(a) + i*conj(b) = (a.x + b.y, b.x - a.y)
+__device__ __forceinline__ f2 conj_add_iconj(f2 a, f2 b) {
+  f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// x * w and x * conj(w), w = (cos, sin) in registers
+__device__ __forceinline__ f2 cmul(f2 x, f2 w) {
+  f2 t;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(w), "v"(x));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(t) : "v"(w), "v"(x));
+  return t;
+}
+__device__ __forceinline__ f2 cmulc(f2 x, f2 w) {
+  f2 t;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(w), "v"(x));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(t) : "v"(w), "v"(x));
+  return t;
+}
+// y += x * h  (complex multiply-accumulate, 2 instructions)
+__device__ __forceinline__ void cmac(f2& y, f2 x, f2 h) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(y) : "v"(x), "v"(h));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(y) : "v"(x), "v"(h));
+}
+// x * (c + i*s) with compile-time c, s (hipcc folds the modifiers itself)
+__device__ __forceinline__ f2 cmul_const(f2 x, float c, float s) {
+  f2 t = mk2(c, c) * x;
+  return pkfma(mk2(-s, s), x.yx, t);
+}
+
 // cos(2*pi*q/64), q = 0..16 (correctly rounded from float64)
 __device__ constexpr float kCos64[17] = {
     1.0f,                 0.99518472667219693f, 0.98078528040323043f, 0.95694033573220882f,
@@ -60,43 +113,40 @@ __host__ __device__ constexpr int bitrev(int v, int bits) {
 // one radix-2 DIT butterfly with twiddle w = exp(DIR*2*pi*i*q/64); q is a
 // compile-time constant after unrolling, so the branches fold away.
 template <int DIR>
-__device__ __forceinline__ void bfly(float& ar, float& ai, float& br, float& bi, int q) {
+__device__ __forceinline__ void bfly(f2& a, f2& b, int q) {
   if (q == 0) {
-    const float tr = ar - br, ti = ai - bi;
-    ar += br; ai += bi; br = tr; bi = ti;
-  } else if (q == 16) {            // w = DIR*i :  w*b = (-DIR*bi, DIR*br)
-    const float wr = (DIR > 0) ? -bi : bi;
-    const float wi = (DIR > 0) ? br : -br;
-    const float tr = ar - wr, ti = ai - wi;
-    ar += wr; ai += wi; br = tr; bi = ti;
+    const f2 t = a - b;
+    a = a + b; b = t;
+  } else if (q == 16) {            // w = DIR*i
+    const f2 t = (DIR > 0) ? add_pi(a, b) : add_mi(a, b);
+    b = (DIR > 0) ? add_mi(a, b) : add_pi(a, b);
+    a = t;
   } else {
     const float c = cos64(q), s = (DIR > 0) ? sin64(q) : -sin64(q);
-    const float tr = fmaf(c, br, fmaf(-s, bi, ar));
-    const float ti = fmaf(c, bi, fmaf(s, br, ai));
-    br = fmaf(2.0f, ar, -tr);
-    bi = fmaf(2.0f, ai, -ti);
-    ar = tr; ai = ti;
+    f2 t = pkfma(mk2(-s, s), b.yx, a);    // (a.re - s*b.im, a.im + s*b.re)
+    t = pkfma(mk2(c, c), b, t);
+    b = pkfma(mk2(2.0f, 2.0f), a, -t);
+    a = t;
   }
 }
 
 // P-point FFT on registers, natural order in, natural order out.
 template <int P, int DIR>
-__device__ __forceinline__ void fft_regs(float (&re)[P], float (&im)[P]) {
+__device__ __forceinline__ void fft_regs(f2 (&v)[P]) {
   constexpr int LG = ilog2(P);
-  float tr[P], ti[P];
+  f2 t[P];
 #pragma unroll
-  for (int i = 0; i < P; ++i) { tr[bitrev(i, LG)] = re[i]; ti[bitrev(i, LG)] = im[i]; }
+  for (int i = 0; i < P; ++i) t[bitrev(i, LG)] = v[i];
 #pragma unroll
   for (int len = 2; len <= P; len <<= 1) {
 #pragma unroll
     for (int blk = 0; blk < P; blk += len) {
 #pragma unroll
-      for (int j = 0; j < len / 2; ++j)
-        bfly<DIR>(tr[blk + j], ti[blk + j], tr[blk + j + len / 2], ti[blk + j + len / 2], j * (64 / len));
+      for (int j = 0; j < len / 2; ++j) bfly<DIR>(t[blk + j], t[blk + j + len / 2], j * (64 / len));
     }
   }
 #pragma unroll
-  for (int i = 0; i < P; ++i) { re[i] = tr[i]; im[i] = ti[i]; }
+  for (int i = 0; i < P; ++i) v[i] = t[i];
 }
 
 // ---- buffer (SRSRC) loads: one VGPR byte offset + SGPR/constant offset per load ----
@@ -110,13 +160,14 @@ __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
 __device__ __forceinline__ float buf_load_f32(BufRsrc r, unsigned voff, unsigned soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
-__device__ __forceinline__ float2 buf_load_f32x2(BufRsrc r, unsigned voff, unsigned soff) {
+__device__ __forceinline__ f2 buf_load_f32x2(BufRsrc r, unsigned voff, unsigned soff) {
   const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+  return mk2(__uint_as_float(v.x), __uint_as_float(v.y));
 }
-__device__ __forceinline__ float4 buf_load_f32x4(BufRsrc r, unsigned voff, unsigned soff) {
+__device__ __forceinline__ f4 buf_load_f32x4(BufRsrc r, unsigned voff, unsigned soff) {
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+  f4 o; o.x = __uint_as_float(v.x); o.y = __uint_as_float(v.y); o.z = __uint_as_float(v.z); o.w = __uint_as_float(v.w);
+  return o;
 }
 
 // ---- cross-lane helpers (DPP quad permutes: VALU rate, no LDS) --------------
@@ -126,6 +177,8 @@ __device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
 __device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
+__device__ __forceinline__ f2 dpp_xor1(f2 v) { return mk2(dpp_xor1(v.x), dpp_xor1(v.y)); }
+__device__ __forceinline__ f2 dpp_xor2(f2 v) { return mk2(dpp_xor2(v.x), dpp_xor2(v.y)); }
 
 template <int P_, int S_>
 struct Geo {
@@ -141,85 +194,97 @@ struct Geo {
 
 // Multiply by the pass-A twiddles and write A[k1][n2] (padded rows).
 //   twA[k1*N2 + n2] = exp(-2*pi*i*n2*k1/T)  (forward sign; conjugated for DIR=+1)
-template <class G, int DIR>
-__device__ __forceinline__ void passA_twiddle_store(float (&re)[G::P], float (&im)[G::P], float2* __restrict__ lseq,
-                                                    int n2, BufRsrc twA) {
-  lseq[n2] = make_float2(re[0], im[0]);
+template <class G>
+__device__ __forceinline__ void passA_twiddle_fetch(f2 (&w)[G::P], int n2, BufRsrc twA) {
   const unsigned off = (unsigned)n2 * 8u;
 #pragma unroll
-  for (int k1 = 1; k1 < G::P; ++k1) {
-    const float2 w = buf_load_f32x2(twA, off, k1 * G::N2 * 8);
-    const float c = w.x, s = (DIR > 0) ? -w.y : w.y;
-    const float xr = re[k1], xi = im[k1];
-    lseq[k1 * G::RS + n2] = make_float2(fmaf(c, xr, -s * xi), fmaf(c, xi, s * xr));
-  }
+  for (int k1 = 1; k1 < G::P; ++k1) w[k1] = buf_load_f32x2(twA, off, k1 * G::N2 * 8);
+}
+template <class G, int DIR>
+__device__ __forceinline__ void passA_twiddle_apply(f2 (&v)[G::P], const f2 (&w)[G::P], f2* __restrict__ lseq, int n2) {
+  lseq[n2] = v[0];
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
+}
+// P-point register FFT + pass-A twiddles + row store.  The whole twiddle batch is requested before
+// the FFT (and pinned there) so its L2 latency hides behind the butterflies.
+template <class G, int DIR>
+__device__ __forceinline__ void passA_fft_twiddle_store(f2 (&v)[G::P], f2* __restrict__ lseq, int n2, BufRsrc twA) {
+  f2 w[G::P];
+  passA_twiddle_fetch<G>(w, n2, twA);
+  __builtin_amdgcn_sched_barrier(0);
+  fft_regs<G::P, DIR>(v);
+  passA_twiddle_apply<G, DIR>(v, w, lseq, n2);
+}
+// same with the twiddle table in LDS
+template <class G, int DIR>
+__device__ __forceinline__ void passA_twiddle_store_lds(f2 (&v)[G::P], f2* __restrict__ lseq, int n2,
+                                                        const f2* __restrict__ twl) {
+  lseq[n2] = v[0];
+  f2 w[G::P];
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) w[k1] = twl[k1 * G::N2 + n2];
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
 }
 
 // Pass-B load: lane (k1, r) of the sequence reads a[S*m + r] of row k1.
 template <class G>
-__device__ __forceinline__ void passB_load(float (&re)[G::P], float (&im)[G::P], const float2* __restrict__ lseq, int tseq) {
+__device__ __forceinline__ void passB_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {
   const int k1 = tseq >> G::LGS, r = tseq & (G::S - 1);
-  const float2* row = lseq + k1 * G::RS + r;
+  const f2* row = lseq + k1 * G::RS + r;
 #pragma unroll
-  for (int m = 0; m < G::P; ++m) {
-    const float2 v = row[G::S * m];
-    re[m] = v.x; im[m] = v.y;
-  }
+  for (int m = 0; m < G::P; ++m) v[m] = row[G::S * m];
 }
 
 // Pass-B compute: register FFT + lane-split finish.  Returns j such that element
 // k of this lane is X[k1 + P*(k + P*j)]   (k1 = tseq >> log2(S)).
-//   twB[r*P + k] = exp(-2*pi*i*r*k/N2)  (forward sign), only used when S > 1.
 template <class G, int DIR>
-__device__ __forceinline__ int passB_compute(float (&re)[G::P], float (&im)[G::P], int tseq, BufRsrc twB) {
-  fft_regs<G::P, DIR>(re, im);
+__device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq) {
+  fft_regs<G::P, DIR>(v);
   if constexpr (G::S == 1) {
     return 0;
   } else {
     const int r = tseq & (G::S - 1);
     // lane twiddle w_N2^(r*k): compile-time roots of unity (N2 <= 128), chosen per lane
     static_assert(G::N2 <= 128, "lane-split twiddles come from the 128th-root table");
-    (void)twB;
-    if (r != 0) {
-#pragma unroll
-      for (int k = 1; k < G::P; ++k) {
-        constexpr int STEP = 128 / G::N2;
-        float c = cos128(STEP * k), s = -sin128(STEP * k);
-        if constexpr (G::S == 4) {
-          const float c2 = cos128(2 * STEP * k), s2 = -sin128(2 * STEP * k);
-          const float c3 = cos128(3 * STEP * k), s3 = -sin128(3 * STEP * k);
-          c = (r == 1) ? c : ((r == 2) ? c2 : c3);
-          s = (r == 1) ? s : ((r == 2) ? s2 : s3);
-        }
-        if (DIR > 0) s = -s;
-        const float xr = re[k], xi = im[k];
-        re[k] = fmaf(c, xr, -s * xi);
-        im[k] = fmaf(c, xi, s * xr);
-      }
-    }
+    constexpr int STEP = 128 / G::N2;
     if constexpr (G::S == 2) {
-      const float sg = r ? -1.0f : 1.0f;
+      if (r != 0) {
 #pragma unroll
-      for (int k = 0; k < G::P; ++k) {
-        re[k] = fmaf(sg, re[k], dpp_xor1(re[k]));
-        im[k] = fmaf(sg, im[k], dpp_xor1(im[k]));
+        for (int k = 1; k < G::P; ++k)
+          v[k] = cmul_const(v[k], cos128(STEP * k), (DIR > 0) ? sin128(STEP * k) : -sin128(STEP * k));
       }
+      const float sg = r ? -1.0f : 1.0f;
+      const f2 sg2 = mk2(sg, sg);
+#pragma unroll
+      for (int k = 0; k < G::P; ++k) v[k] = pkfma(sg2, v[k], dpp_xor1(v[k]));
       return r;
     } else {  // S == 4 : radix-4 across the quad, output order bit-reversed
-      const float s2 = (r & 2) ? -1.0f : 1.0f;
-      const float s1 = (r & 1) ? -1.0f : 1.0f;
+      if (r != 0) {
+#pragma unroll
+        for (int k = 1; k < G::P; ++k) {
+          const float c1 = cos128(STEP * k), s1 = -sin128(STEP * k);
+          const float c2 = cos128(2 * STEP * k), s2 = -sin128(2 * STEP * k);
+          const float c3 = cos128(3 * STEP * k), s3 = -sin128(3 * STEP * k);
+          const float c = (r == 1) ? c1 : ((r == 2) ? c2 : c3);
+          float s = (r == 1) ? s1 : ((r == 2) ? s2 : s3);
+          if (DIR > 0) s = -s;
+          const f2 x = v[k];
+          v[k] = mk2(fmaf(c, x.x, -s * x.y), fmaf(c, x.y, s * x.x));
+        }
+      }
+      const float f2s = (r & 2) ? -1.0f : 1.0f;
+      const float f1s = (r & 1) ? -1.0f : 1.0f;
+      const f2 sg2 = mk2(f2s, f2s), sg1 = mk2(f1s, f1s);
       const bool rot = (r == 3);
 #pragma unroll
       for (int k = 0; k < G::P; ++k) {
-        float ar = fmaf(s2, re[k], dpp_xor2(re[k]));
-        float ai = fmaf(s2, im[k], dpp_xor2(im[k]));
+        f2 a = pkfma(sg2, v[k], dpp_xor2(v[k]));
         // lane 3 holds (E1 - E3): multiply by w4 = DIR*i
-        const float rr = (DIR > 0) ? -ai : ai;
-        const float ri = (DIR > 0) ? ar : -ar;
-        ar = rot ? rr : ar;
-        ai = rot ? ri : ai;
-        re[k] = fmaf(s1, ar, dpp_xor1(ar));
-        im[k] = fmaf(s1, ai, dpp_xor1(ai));
+        const f2 ar = (DIR > 0) ? mk2(-a.y, a.x) : mk2(a.y, -a.x);
+        a = rot ? ar : a;
+        v[k] = pkfma(sg1, a, dpp_xor1(a));
       }
       return ((r & 1) << 1) | (r >> 1);
     }

@@ -45,46 +45,39 @@ __device__ __forceinline__ int tap_src(int p, int dil, int k) {
 // leaves the natural-order spectrum in lseq.  Contains two barriers: every thread of the
 // workgroup must call it (idle threads pass act = false).
 template <class G>
-__device__ __forceinline__ void fwd_from_regs(float (&re)[G::P], float (&im)[G::P], float2* lseq, int tseq, bool act,
-                                              BufRsrc twA, BufRsrc twB) {
+__device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA) {
   if (act) {
-    fft_regs<G::P, -1>(re, im);
-    passA_twiddle_store<G, -1>(re, im, lseq, tseq, twA);
+    passA_fft_twiddle_store<G, -1>(v, lseq, tseq, twA);
   }
   __syncthreads();
-  if (act) passB_load<G>(re, im, lseq, tseq);
+  if (act) passB_load<G>(v, lseq, tseq);
   __syncthreads();
   if (act) {
-    const int j = passB_compute<G, -1>(re, im, tseq, twB);
+    const int j = passB_compute<G, -1>(v, tseq);
     const int k1 = tseq >> G::LGS;
-    float2* dst = lseq + G::nat(k1 + G::P * G::P * j);
+    f2* dst = lseq + G::nat(k1 + G::P * G::P * j);
 #pragma unroll
-    for (int k = 0; k < G::P; ++k) dst[G::P * k] = make_float2(re[k], im[k]);
+    for (int k = 0; k < G::P; ++k) dst[G::P * k] = v[k];
   }
 }
 
 // inverse passes from the natural-order spectrum in lseq; on return element k of this lane is
 // sample n = o1 + P*k + P*P*j (o1 = tseq >> log2 S, j returned).  Two barriers inside.
 template <class G>
-__device__ __forceinline__ int inv_to_regs(float (&re)[G::P], float (&im)[G::P], float2* lseq, int tseq, bool act,
-                                           BufRsrc twA, BufRsrc twB) {
+__device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA) {
   if (act) {
 #pragma unroll
-    for (int i1 = 0; i1 < G::P; ++i1) {
-      const float2 v = lseq[G::nat(G::N2 * i1 + tseq)];
-      re[i1] = v.x; im[i1] = v.y;
-    }
+    for (int i1 = 0; i1 < G::P; ++i1) v[i1] = lseq[G::nat(G::N2 * i1 + tseq)];
   }
   __syncthreads();
   if (act) {
-    fft_regs<G::P, +1>(re, im);
-    passA_twiddle_store<G, +1>(re, im, lseq, tseq, twA);
+    passA_fft_twiddle_store<G, +1>(v, lseq, tseq, twA);
   }
   __syncthreads();
   int j = 0;
   if (act) {
-    passB_load<G>(re, im, lseq, tseq);
-    j = passB_compute<G, +1>(re, im, tseq, twB);
+    passB_load<G>(v, lseq, tseq);
+    j = passB_compute<G, +1>(v, tseq);
   }
   return j;
 }
@@ -99,9 +92,9 @@ struct SeqLayout {
 // ------------------------------------------------------------------------------------------ rows_r2c
 struct RowsR2CArgs {
   const float* src;      // signal (B, C, [Z,] Y, X) or kernel taps (Co, Cig, [Kz,] Ky, Kx)
-  float2* dst;           // [(a*NC + c)][Fx][NYa]
-  const float2* twA;
-  const float2* twB;
+  f2* dst;           // [(a*NC + c)][Fx][NYa]
+  const f2* twA;
+  const f2* twB;
   int from_kernel;       // 0: signal with padding maps, 1: dilated kernel taps
   AxisMap mx, my, mz;    // signal: per-axis padding maps (mz unused for 2-D)
   int kx, ky, kz, dx, dy, dz;   // kernel: taps and dilation per axis
@@ -117,9 +110,8 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
   constexpr int RB = 2 * NSEQ;
   static_assert(NT == NSEQ * G::TS, "one thread slot per sequence point group");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
@@ -128,7 +120,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   const int img = id / a.NC;
   const int y0 = yb * RB;
 
-  float re[P], im[P];
+  f2 v[P];
   {
     // two rows per sequence
     const float* rows[2];
@@ -147,43 +139,40 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
       ok[h] = ys >= 0 && zs >= 0;
       rows[h] = a.src + (((size_t)img * a.SZ + (ok[h] ? zs : 0)) * a.SY + (ok[h] ? ys : 0)) * a.SX;
     }
-    float2* col = lds + sq * LSEQP + tseq;
+    f2* col = lds + sq * LSEQP + tseq;
 #pragma unroll 1
     for (int n1 = 0; n1 < P; ++n1) {
       const int xp = G::N2 * n1 + tseq;
       const int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
       const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
       const float v1 = (ok[1] && xs >= 0) ? rows[1][xs] : 0.f;
-      col[n1 * G::RS] = make_float2(v0, v1);
+      col[n1 * G::RS] = mk2(v0, v1);
     }
 #pragma unroll
-    for (int n1 = 0; n1 < P; ++n1) {
-      const float2 v = col[n1 * G::RS];
-      re[n1] = v.x; im[n1] = v.y;
-    }
+    for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
   }
-  fwd_from_regs<G>(re, im, lds + sq * LSEQP, tseq, true, twA, twB);
+  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA);
   __syncthreads();
   // unpack the two real spectra of every pair and store transposed: RB rows contiguous per bin
-  float2* out = a.dst + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+  f2* out = a.dst + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
   for (int idx = tid; idx < a.Fx * RB; idx += NT) {
     const int r = idx % RB, fx = idx / RB;
     if (y0 + r >= a.NY) continue;
-    const float2* z = lds + (r >> 1) * LSEQP;
-    const float2 zf = z[G::nat(fx)], zg = z[G::nat((T - fx) & (T - 1))];
-    float2 v;
-    if ((r & 1) == 0) v = make_float2(0.5f * (zf.x + zg.x), 0.5f * (zf.y - zg.y));
-    else v = make_float2(0.5f * (zf.y + zg.y), 0.5f * (zg.x - zf.x));
-    out[(size_t)fx * a.NYa + r] = v;
+    const f2* z = lds + (r >> 1) * LSEQP;
+    const f2 zf = z[G::nat(fx)], zg = z[G::nat((T - fx) & (T - 1))];
+    f2 xv;
+    if ((r & 1) == 0) xv = mk2(0.5f * (zf.x + zg.x), 0.5f * (zf.y - zg.y));
+    else xv = mk2(0.5f * (zf.y + zg.y), 0.5f * (zg.x - zf.x));
+    out[(size_t)fx * a.NYa + r] = xv;
   }
 }
 
 // ------------------------------------------------------------------------------------------ c2c_fwd
 struct C2CArgs {
-  const float2* src;
-  float2* dst;
-  const float2* twA;
-  const float2* twB;
+  const f2* src;
+  f2* dst;
+  const f2* twA;
+  const f2* twB;
   // sequence (a, c, bn): src element n at a*sa + c*sc + bn*sb + n        (n < NLEN, zero beyond)
   // dst: transposed  a*ta + c*tc + f*tf + bn   (store_mode 0, forward)
   //      weights     final kernel-spectrum layout (store_mode 1, forward; conj + scale + i-pair interleave)
@@ -204,9 +193,8 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
   constexpr int T = G::T;
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
   static_assert(NT == NSEQ * G::TS, "thread count");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nbb = (a.NB + NSEQ - 1) / NSEQ;
   int id = blockIdx.x;
@@ -216,21 +204,19 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
   const int bn0 = bb * NSEQ;
   const bool act = bn0 + sq < a.NB;
 
-  float re[P], im[P];
+  f2 v[P];
   {
-    const float2* s = a.src + (size_t)img * a.sa + (size_t)c * a.sc + (size_t)(bn0 + sq) * a.sb;
+    const f2* s = a.src + (size_t)img * a.sa + (size_t)c * a.sc + (size_t)(bn0 + sq) * a.sb;
 #pragma unroll
     for (int n1 = 0; n1 < P; ++n1) {
       const int n = G::N2 * n1 + tseq;
-      float2 v = make_float2(0.f, 0.f);
-      if (act && n < a.NLEN) v = s[n];
-      re[n1] = v.x; im[n1] = v.y;
+      v[n1] = (act && n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
     }
   }
-  fwd_from_regs<G>(re, im, lds + sq * LSEQP, tseq, act, twA, twB);
+  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, act, twA);
   __syncthreads();
   if (a.store_mode == 0) {
-    float2* out = a.dst + (size_t)img * a.ta + (size_t)c * a.tc + bn0;
+    f2* out = a.dst + (size_t)img * a.ta + (size_t)c * a.tc + bn0;
     for (int idx = tid; idx < T * NSEQ; idx += NT) {
       const int r = idx % NSEQ, f = idx / NSEQ;
       if (bn0 + r < a.NB) out[(size_t)f * a.tf + r] = lds[r * LSEQP + G::nat(f)];
@@ -240,12 +226,12 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
     // columns (fx or (fx,fy)) of one (o, i) image and c is unused (NC == 1)
     const int o_all = img / a.Cig, i = img % a.Cig;
     const int g = o_all / a.Cog, o = o_all % a.Cog;
-    float2* base = a.dst + (((size_t)(g * a.Cog_pad + o) * (a.Cig_pad / 2) + (i >> 1)) * a.NB) * T * 2 + (i & 1);
+    f2* base = a.dst + (((size_t)(g * a.Cog_pad + o) * (a.Cig_pad / 2) + (i >> 1)) * a.NB) * T * 2 + (i & 1);
     for (int idx = tid; idx < T * NSEQ; idx += NT) {
       const int f = idx % T, r = idx / T;
       if (bn0 + r < a.NB) {
-        const float2 v = lds[r * LSEQP + G::nat(f)];
-        base[((size_t)(bn0 + r) * T + f) * 2] = make_float2(v.x * a.scale, -v.y * a.scale);
+        const f2 wv = lds[r * LSEQP + G::nat(f)];
+        base[((size_t)(bn0 + r) * T + f) * 2] = mk2(wv.x * a.scale, -wv.y * a.scale);
       }
     }
   }
@@ -258,9 +244,8 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   constexpr int T = G::T;
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
   static_assert(NT == NSEQ * G::TS, "thread count");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nbb = (a.NB + NSEQ - 1) / NSEQ;
   int id = blockIdx.x;
@@ -270,36 +255,34 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   const int bn0 = bb * NSEQ;
   const bool act = bn0 + sq < a.NB;
   {
-    const float2* in = a.src + (size_t)img * a.sa + (size_t)c * a.sc + bn0;
+    const f2* in = a.src + (size_t)img * a.sa + (size_t)c * a.sc + bn0;
     for (int idx = tid; idx < T * NSEQ; idx += NT) {
       const int r = idx % NSEQ, f = idx / NSEQ;
-      float2 v = make_float2(0.f, 0.f);
-      if (bn0 + r < a.NB) v = in[(size_t)f * a.sb + r];
-      lds[r * LSEQP + G::nat(f)] = v;
+      lds[r * LSEQP + G::nat(f)] = (bn0 + r < a.NB) ? in[(size_t)f * a.sb + r] : mk2(0.f, 0.f);
     }
   }
   __syncthreads();
-  float re[P], im[P];
-  const int j = inv_to_regs<G>(re, im, lds + sq * LSEQP, tseq, act, twA, twB);
+  f2 v[P];
+  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, act, twA);
   if (act) {
-    float2* out = a.dst + (size_t)img * a.ta + (size_t)(bn0 + sq) * a.tb + (size_t)c * a.tc;
+    f2* out = a.dst + (size_t)img * a.ta + (size_t)(bn0 + sq) * a.tb + (size_t)c * a.tc;
     const int nbase = (tseq >> G::LGS) + P * P * j;
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       const int n = nbase + P * k;
       const int idx = n / a.stride;
-      if (n < a.NV && idx * a.stride == n) out[idx] = make_float2(re[k], im[k]);
+      if (n < a.NV && idx * a.stride == n) out[idx] = v[k];
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ rows_c2r
 struct RowsC2RArgs {
-  const float2* src;     // [(a*NC + c)][Fx][NYa]  (a = b*Cout + o)
+  const f2* src;     // [(a*NC + c)][Fx][NYa]  (a = b*Cout + o)
   float* dst;            // (B, Cout, [Zo,] Yo, Xo)
   const float* bias;
-  const float2* twA;
-  const float2* twB;
+  const f2* twA;
+  const f2* twB;
   int NA, NC, NY, NYa, Fx, Cout;
   int NV, stride, Xo;    // valid stride-1 samples along x, decimation, output row length
 };
@@ -311,9 +294,8 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
   constexpr int RB = 2 * NSEQ;
   static_assert(NT == NSEQ * G::TS, "thread count");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
@@ -324,24 +306,24 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   {
     // rows 2s (-> real part) and 2s+1 (-> imaginary part) share one complex inverse FFT:
     // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
-    const float2* in = a.src + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+    const f2* in = a.src + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
     for (int idx = tid; idx < a.Fx * NSEQ; idx += NT) {
       const int s = idx % NSEQ, fx = idx / NSEQ;
-      float2 ya = make_float2(0.f, 0.f), yb2 = make_float2(0.f, 0.f);
+      f2 ya = mk2(0.f, 0.f), yb2 = mk2(0.f, 0.f);
       if (y0 + 2 * s < a.NY) ya = in[(size_t)fx * a.NYa + 2 * s];
       if (y0 + 2 * s + 1 < a.NY) yb2 = in[(size_t)fx * a.NYa + 2 * s + 1];
-      float2* z = lds + s * LSEQP;
+      f2* z = lds + s * LSEQP;
       if (fx == 0 || fx == T / 2) {
-        z[G::nat(fx)] = make_float2(ya.x, yb2.x);          // both spectra are real at the self-paired bins
+        z[G::nat(fx)] = mk2(ya.x, yb2.x);          // both spectra are real at the self-paired bins
       } else {
-        z[G::nat(fx)] = make_float2(ya.x - yb2.y, ya.y + yb2.x);
-        z[G::nat(T - fx)] = make_float2(ya.x + yb2.y, yb2.x - ya.y);
+        z[G::nat(fx)] = mk2(ya.x - yb2.y, ya.y + yb2.x);
+        z[G::nat(T - fx)] = mk2(ya.x + yb2.y, yb2.x - ya.y);
       }
     }
   }
   __syncthreads();
-  float re[P], im[P];
-  const int j = inv_to_regs<G>(re, im, lds + sq * LSEQP, tseq, true, twA, twB);
+  f2 v[P];
+  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, true, twA);
   const int ya_row = y0 + 2 * sq;
   const float b = a.bias ? a.bias[img % a.Cout] : 0.f;
   float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;
@@ -353,8 +335,8 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
     const int n = nbase + P * k;
     const int idx = n / a.stride;
     if (n < a.NV && idx * a.stride == n) {
-      if (has0) o0[idx] = re[k] + b;
-      if (has1) o1[idx] = im[k] + b;
+      if (has0) o0[idx] = v[k].x + b;
+      if (has1) o1[idx] = v[k].y + b;
     }
   }
 }
@@ -362,11 +344,11 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
 // ------------------------------------------------------------------------------------------ fusedc
 // Outermost-axis pass: CIB complex sequences (one per input channel of the group) per workgroup.
 struct FusedCArgs {
-  const float2* src;     // [(b*Cin + ci)][col][NLEN]   contiguous along the fused axis
-  const float4* wspec;   // [g][Cog_pad][Cig_pad/2][ncol][T] float4 = {H(o,2ip), H(o,2ip+1)}
-  float2* dst;           // [(b*Cout + co)][col][NVo]    valid (decimated) samples
-  const float2* twA;
-  const float2* twB;
+  const f2* src;     // [(b*Cin + ci)][col][NLEN]   contiguous along the fused axis
+  const f4* wspec;   // [g][Cog_pad][Cig_pad/2][ncol][T] f4 = {H(o,2ip), H(o,2ip+1)}
+  f2* dst;           // [(b*Cout + co)][col][NVo]    valid (decimated) samples
+  const f2* twA;
+  const f2* twB;
   int B, Cin, Cout, G, Cig, Cog, Cig_pad, Cog_pad, cob, n_ochunks;
   int ncol, NLEN;        // columns per image, valid input length (zero beyond)
   int Kd, V, ntiles, Lfull, NVo, stride;
@@ -379,9 +361,8 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   constexpr int T = G::T;
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
   static_assert(NT == CIB * G::TS, "one sequence per channel of the chunk");
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
 
   // id = ((((b*ntiles + tile)*n_ochunks + oc)*G + g)*ncol + col): neighbouring workgroups share (g, oc)
@@ -393,63 +374,56 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   const int tile = id % a.ntiles;
   const int b = id / a.ntiles;
 
-  float2* zin = lds;
-  float2* vout = a.accumulate ? lds + CIB * LSEQP : lds;
+  f2* zin = lds;
+  f2* vout = a.accumulate ? lds + CIB * LSEQP : lds;
   const int n_ichunks = a.Cig_pad / CIB;
   const int t0 = tile * a.V;
-  const size_t wcol = (size_t)a.ncol * T;                          // float4 per (o, ip)
-  const float4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)col * T;
+  const size_t wcol = (size_t)a.ncol * T;                          // f4 per (o, ip)
+  const f4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)col * T;
 
   for (int ic = 0; ic < n_ichunks; ++ic) {
     {
       const int ci = ic * CIB + sq;
       const bool has = ci < a.Cig;
-      const float2* s = a.src + (((size_t)b * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
-      float re[P], im[P];
+      const f2* s = a.src + (((size_t)b * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
+      f2 v[P];
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
         const int n = G::N2 * n1 + tseq;
-        float2 v = make_float2(0.f, 0.f);
-        if (has && t0 + n < a.NLEN) v = s[n];
-        re[n1] = v.x; im[n1] = v.y;
+        v[n1] = (has && t0 + n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
       }
-      fwd_from_regs<G>(re, im, zin + sq * LSEQP, tseq, true, twA, twB);
+      fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA);
     }
     __syncthreads();
     // mix: every bin is independent in complex mode
     for (int f = tid; f < T; f += NT) {
-      float xr[CIB], xi[CIB];
+      f2 x[CIB];
 #pragma unroll
-      for (int i = 0; i < CIB; ++i) {
-        const float2 z = zin[i * LSEQP + G::nat(f)];
-        xr[i] = z.x; xi[i] = z.y;
-      }
+      for (int i = 0; i < CIB; ++i) x[i] = zin[i * LSEQP + G::nat(f)];
 #pragma unroll 1
       for (int o = 0; o < a.cob; ++o) {
-        const float4* w = wgrp + ((size_t)(oc * a.cob + o) * (a.Cig_pad / 2) + ic * (CIB / 2)) * wcol + f;
-        float yr = 0.f, yi = 0.f;
+        const f4* w = wgrp + ((size_t)(oc * a.cob + o) * (a.Cig_pad / 2) + ic * (CIB / 2)) * wcol + f;
+        f2 y = mk2(0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < CIB / 2; ++p) {
-          const float4 h = w[(size_t)p * wcol];
-          yr = fmaf(xr[2 * p], h.x, yr); yr = fmaf(-xi[2 * p], h.y, yr);
-          yi = fmaf(xr[2 * p], h.y, yi); yi = fmaf(xi[2 * p], h.x, yi);
-          yr = fmaf(xr[2 * p + 1], h.z, yr); yr = fmaf(-xi[2 * p + 1], h.w, yr);
-          yi = fmaf(xr[2 * p + 1], h.w, yi); yi = fmaf(xi[2 * p + 1], h.z, yi);
+          const f4 h = w[(size_t)p * wcol];
+          cmac(y, x[2 * p], h.xy);
+          cmac(y, x[2 * p + 1], h.zw);
         }
-        float2* pv = vout + o * LSEQP + G::nat(f);
-        if (ic != 0) { const float2 old = *pv; yr += old.x; yi += old.y; }
-        *pv = make_float2(yr, yi);
+        f2* pv = vout + o * LSEQP + G::nat(f);
+        if (ic != 0) y += *pv;
+        *pv = y;
       }
     }
     __syncthreads();
   }
   // inverse + store of the valid, decimated samples
-  float re[P], im[P];
+  f2 v[P];
   const bool act = sq < a.cob;
-  const int j = inv_to_regs<G>(re, im, vout + sq * LSEQP, tseq, act, twA, twB);
+  const int j = inv_to_regs<G>(v, vout + sq * LSEQP, tseq, act, twA);
   const int co = oc * a.cob + sq;
   if (act && co < a.Cog) {
-    float2* out = a.dst + (((size_t)b * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
+    f2* out = a.dst + (((size_t)b * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
     const int limit = min(a.V, a.Lfull - t0);
     const int nbase = (tseq >> G::LGS) + P * P * j;
 #pragma unroll
@@ -457,7 +431,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
       const int n = nbase + P * k;
       const int t = t0 + n;
       const int idx = t / a.stride;
-      if (n < limit && idx * a.stride == t) out[idx] = make_float2(re[k], im[k]);
+      if (n < limit && idx * a.stride == t) out[idx] = v[k];
     }
   }
 }

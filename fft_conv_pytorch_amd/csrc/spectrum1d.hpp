@@ -15,9 +15,9 @@ namespace fc {
 
 struct Spec1dArgs {
   const float* w;      // (Cout, Cig, K)
-  float4* wspec;
-  const float2* twA;
-  const float2* twB;
+  f4* wspec;
+  const f2* twA;
+  const f2* twB;
   int G, Cig, Cog, Cig_pad, Cog_pad, K, dil, nseq;
 };
 
@@ -26,21 +26,20 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
   constexpr int SEQ_PER_WG = NT / G::TS;
-  extern __shared__ __attribute__((aligned(16))) float2 lds[];
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const int tid = threadIdx.x;
   const int sl = tid / G::TS, tseq = tid % G::TS;
   const int seq = blockIdx.x * SEQ_PER_WG + sl;
   const bool act = seq < a.nseq;
-  float2* z = lds + sl * G::LSEQ;
+  f2* z = lds + sl * G::LSEQ;
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
-  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
 
   const int npi = a.Cig_pad / 2;
   const int ip = act ? seq % npi : 0;
   const int o = act ? (seq / npi) % a.Cog_pad : 0;
   const int g = act ? seq / (npi * a.Cog_pad) : 0;
   {
-    float re[P], im[P];
+    f2 v[P];
     const bool has0 = act && o < a.Cog && 2 * ip < a.Cig;
     const bool has1 = act && o < a.Cog && 2 * ip + 1 < a.Cig;
     const float* w0 = a.w + ((size_t)(g * a.Cog + o) * a.Cig + 2 * ip) * a.K;
@@ -50,37 +49,36 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
       const int n = G::N2 * n1 + tseq;
       const int tap = n / a.dil;
       const bool hit = (tap * a.dil == n) && tap < a.K;
-      re[n1] = (hit && has0) ? w0[tap] : 0.f;
-      im[n1] = (hit && has1) ? w1[tap] : 0.f;
+      v[n1].x = (hit && has0) ? w0[tap] : 0.f;
+      v[n1].y = (hit && has1) ? w1[tap] : 0.f;
     }
-    fft_regs<P, -1>(re, im);
-    passA_twiddle_store<G, -1>(re, im, z, tseq, twA);
+    passA_fft_twiddle_store<G, -1>(v, z, tseq, twA);
   }
   __syncthreads();
   {
-    float re[P], im[P];
-    passB_load<G>(re, im, z, tseq);
+    f2 v[P];
+    passB_load<G>(v, z, tseq);
     __syncthreads();
-    const int j = passB_compute<G, -1>(re, im, tseq, twB);
+    const int j = passB_compute<G, -1>(v, tseq);
     const int k1 = tseq >> G::LGS;
-    float2* dst = z + G::nat(k1 + P * P * j);
+    f2* dst = z + G::nat(k1 + P * P * j);
 #pragma unroll
-    for (int k = 0; k < P; ++k) dst[P * k] = make_float2(re[k], im[k]);
+    for (int k = 0; k < P; ++k) dst[P * k] = v[k];
   }
   __syncthreads();
   if (!act) return;
   const float sc = 0.5f / (float)T;
-  float4* out = a.wspec + (size_t)seq * (T / 2);
+  f4* out = a.wspec + (size_t)seq * (T / 2);
   for (int f = tseq; f < T / 2; f += G::TS) {
-    float4 h;
+    f4 h;
     if (f == 0) {
-      const float2 z0 = z[G::nat(0)], zh = z[G::nat(T / 2)];
-      h = make_float4(z0.x * sc, zh.x * sc, z0.y * sc, zh.y * sc);
+      const f2 z0 = z[G::nat(0)], zh = z[G::nat(T / 2)];
+      h.x = z0.x * sc; h.y = zh.x * sc; h.z = z0.y * sc; h.w = zh.y * sc;
     } else {
-      const float2 zf = z[G::nat(f)], zg = z[G::nat(T - f)];
+      const f2 zf = z[G::nat(f)], zg = z[G::nat(T - f)];
       // W_a = (Zf + conj(Zg))/2, W_b = (Zf - conj(Zg))/(2i); H = conj(W)/(2T)
       const float h2 = 0.5f * sc;
-      h = make_float4((zf.x + zg.x) * h2, -(zf.y - zg.y) * h2, (zf.y + zg.y) * h2, -(zg.x - zf.x) * h2);
+      h.x = (zf.x + zg.x) * h2; h.y = -(zf.y - zg.y) * h2; h.z = (zf.y + zg.y) * h2; h.w = -(zg.x - zf.x) * h2;
     }
     out[f] = h;
   }

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   // buffer descriptors from uniform values only (no waterfall loops)
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const BufRsrc xg = make_rsrc(a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L, (unsigned)a.Cig * (unsigned)a.L * 4u);
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       if (seq0 < NPI) passB_load<G>(v, zin + seq0 * G::LSEQ, tseq);
       __syncthreads();
       if (seq0 < NPI) {
-        const int j = passB_compute<G, -1>(v, tseq);
+        const int j = passB_compute<G, -1>(v, tseq, twB);
         const int k1 = tseq >> G::LGS;
         f2* dst = zin + seq0 * G::LSEQ + G::nat(k1 + P * P * j);   // nat() pad is constant per j block
 #pragma unroll
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
     const int sq = seq0;
     f2 v[P];
     passB_load<G>(v, vout + sq * G::LSEQ, tseq);
-    const int j = passB_compute<G, +1>(v, tseq);
+    const int j = passB_compute<G, +1>(v, tseq, twB);
     const int o1 = tseq >> G::LGS;
     const int co0 = oc * a.cob + 2 * sq;           // out channel within the group
     const bool has0 = co0 < a.Cog, has1 = co0 + 1 < a.Cog;

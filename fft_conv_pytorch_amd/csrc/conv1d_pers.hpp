@@ -54,6 +54,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 
   for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
   const PadMap pm = make_padmap(a.pad_mode, a.L);
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   __syncthreads();
 
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       if (act_in) passB_load<G>(v, zseq, tseq);
       __syncthreads();
       if (act_in) {
-        const int j = passB_compute<G, -1>(v, tseq);
+        const int j = passB_compute<G, -1>(v, tseq, twB);
         const int k1 = tseq >> G::LGS;
         f2* dst = zseq + G::nat(k1 + P * P * j);
 #pragma unroll
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     if (act_out) {
       f2 v[P];
       passB_load<G>(v, zseq, tseq);
-      const int j = passB_compute<G, +1>(v, tseq);
+      const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;
       const int t0 = tile * a.V;
       const int limit = min(a.V, a.Lfull - t0);

@@ -158,7 +158,9 @@ static int plan_1d(fc_plan* p) {
     // work model: FFT passes + channel mix per tile; the largest tile runs one
     // workgroup per CU (LDS), which costs latency hiding
     double cost = (double)nt * t->T * (2.0 * std::log2((double)t->T) + 4.0 + p->CB);
-    if (lds > 80 * 1024) cost *= 1.25;
+    // measured (cfgD, MI355X): one 512-thread workgroup per CU and the four-lane split cost the
+    // 4096 tile ~1.7x per sample of tile; it only wins when the kernel is nearly as long as 2048
+    if (lds > 80 * 1024) cost *= 1.7;
     if (!best || cost < best_cost) { best = t; best_cost = cost; }
   }
   if (!best) {

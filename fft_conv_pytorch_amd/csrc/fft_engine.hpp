@@ -239,9 +239,22 @@ __device__ __forceinline__ void passB_load(f2 (&v)[G::P], const f2* __restrict__
 
 // Pass-B compute: register FFT + lane-split finish.  Returns j such that element
 // k of this lane is X[k1 + P*(k + P*j)]   (k1 = tseq >> log2(S)).
+//   twB[r*P + k] = exp(-2*pi*i*r*k/N2) (forward sign): used by the S = 4 split, whose per-lane
+//   twiddles differ between the three non-trivial lanes of a quad (S = 2 uses compile-time roots)
 template <class G, int DIR>
-__device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq) {
-  fft_regs<G::P, DIR>(v);
+__device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq, BufRsrc twB) {
+  if constexpr (G::S == 4) {
+    const int r4 = tseq & 3;
+    f2 w[G::P];
+#pragma unroll
+    for (int k = 1; k < G::P; ++k) w[k] = buf_load_f32x2(twB, (unsigned)(r4 * G::P * 8), k * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    fft_regs<G::P, DIR>(v);
+#pragma unroll
+    for (int k = 1; k < G::P; ++k) v[k] = (DIR > 0) ? cmulc(v[k], w[k]) : cmul(v[k], w[k]);
+  } else {
+    fft_regs<G::P, DIR>(v);
+  }
   if constexpr (G::S == 1) {
     return 0;
   } else {
@@ -260,20 +273,7 @@ __device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq) {
 #pragma unroll
       for (int k = 0; k < G::P; ++k) v[k] = pkfma(sg2, v[k], dpp_xor1(v[k]));
       return r;
-    } else {  // S == 4 : radix-4 across the quad, output order bit-reversed
-      if (r != 0) {
-#pragma unroll
-        for (int k = 1; k < G::P; ++k) {
-          const float c1 = cos128(STEP * k), s1 = -sin128(STEP * k);
-          const float c2 = cos128(2 * STEP * k), s2 = -sin128(2 * STEP * k);
-          const float c3 = cos128(3 * STEP * k), s3 = -sin128(3 * STEP * k);
-          const float c = (r == 1) ? c1 : ((r == 2) ? c2 : c3);
-          float s = (r == 1) ? s1 : ((r == 2) ? s2 : s3);
-          if (DIR > 0) s = -s;
-          const f2 x = v[k];
-          v[k] = mk2(fmaf(c, x.x, -s * x.y), fmaf(c, x.y, s * x.x));
-        }
-      }
+    } else {  // S == 4 : radix-4 across the quad, output order bit-reversed (lane twiddles applied above)
       const float f2s = (r & 2) ? -1.0f : 1.0f;
       const float f1s = (r & 1) ? -1.0f : 1.0f;
       const f2 sg2 = mk2(f2s, f2s), sg1 = mk2(f1s, f1s);

@@ -45,7 +45,7 @@ __device__ __forceinline__ int tap_src(int p, int dil, int k) {
 // leaves the natural-order spectrum in lseq.  Contains two barriers: every thread of the
 // workgroup must call it (idle threads pass act = false).
 template <class G>
-__device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA) {
+__device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA, BufRsrc twB) {
   if (act) {
     passA_fft_twiddle_store<G, -1>(v, lseq, tseq, twA);
   }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq,
   if (act) passB_load<G>(v, lseq, tseq);
   __syncthreads();
   if (act) {
-    const int j = passB_compute<G, -1>(v, tseq);
+    const int j = passB_compute<G, -1>(v, tseq, twB);
     const int k1 = tseq >> G::LGS;
     f2* dst = lseq + G::nat(k1 + G::P * G::P * j);
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq,
 // inverse passes from the natural-order spectrum in lseq; on return element k of this lane is
 // sample n = o1 + P*k + P*P*j (o1 = tseq >> log2 S, j returned).  Two barriers inside.
 template <class G>
-__device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA) {
+__device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA, BufRsrc twB) {
   if (act) {
 #pragma unroll
     for (int i1 = 0; i1 < G::P; ++i1) v[i1] = lseq[G::nat(G::N2 * i1 + tseq)];
@@ -77,7 +77,7 @@ __device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bo
   int j = 0;
   if (act) {
     passB_load<G>(v, lseq, tseq);
-    j = passB_compute<G, +1>(v, tseq);
+    j = passB_compute<G, +1>(v, tseq, twB);
   }
   return j;
 }
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   static_assert(NT == NSEQ * G::TS, "one thread slot per sequence point group");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
 #pragma unroll
     for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
   }
-  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA);
+  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
   __syncthreads();
   // unpack the two real spectra of every pair and store transposed: RB rows contiguous per bin
   f2* out = a.dst + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
   static_assert(NT == NSEQ * G::TS, "thread count");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nbb = (a.NB + NSEQ - 1) / NSEQ;
   int id = blockIdx.x;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
       v[n1] = (act && n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
     }
   }
-  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, act, twA);
+  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
   __syncthreads();
   if (a.store_mode == 0) {
     f2* out = a.dst + (size_t)img * a.ta + (size_t)c * a.tc + bn0;
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   static_assert(NT == NSEQ * G::TS, "thread count");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nbb = (a.NB + NSEQ - 1) / NSEQ;
   int id = blockIdx.x;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   }
   __syncthreads();
   f2 v[P];
-  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, act, twA);
+  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
   if (act) {
     f2* out = a.dst + (size_t)img * a.ta + (size_t)(bn0 + sq) * a.tb + (size_t)c * a.tc;
     const int nbase = (tseq >> G::LGS) + P * P * j;
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   static_assert(NT == NSEQ * G::TS, "thread count");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   }
   __syncthreads();
   f2 v[P];
-  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, true, twA);
+  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
   const int ya_row = y0 + 2 * sq;
   const float b = a.bias ? a.bias[img % a.Cout] : 0.f;
   float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   static_assert(NT == CIB * G::TS, "one sequence per channel of the chunk");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
 
   // id = ((((b*ntiles + tile)*n_ochunks + oc)*G + g)*ncol + col): neighbouring workgroups share (g, oc)
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
         const int n = G::N2 * n1 + tseq;
         v[n1] = (has && t0 + n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
       }
-      fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA);
+      fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA, twB);
     }
     __syncthreads();
     // mix: every bin is independent in complex mode
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   // inverse + store of the valid, decimated samples
   f2 v[P];
   const bool act = sq < a.cob;
-  const int j = inv_to_regs<G>(v, vout + sq * LSEQP, tseq, act, twA);
+  const int j = inv_to_regs<G>(v, vout + sq * LSEQP, tseq, act, twA, twB);
   const int co = oc * a.cob + sq;
   if (act && co < a.Cog) {
     f2* out = a.dst + (((size_t)b * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;

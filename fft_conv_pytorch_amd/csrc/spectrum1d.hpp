@@ -33,6 +33,7 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
   const bool act = seq < a.nseq;
   f2* z = lds + sl * G::LSEQ;
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
 
   const int npi = a.Cig_pad / 2;
   const int ip = act ? seq % npi : 0;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
     f2 v[P];
     passB_load<G>(v, z, tseq);
     __syncthreads();
-    const int j = passB_compute<G, -1>(v, tseq);
+    const int j = passB_compute<G, -1>(v, tseq, twB);
     const int k1 = tseq >> G::LGS;
     f2* dst = z + G::nat(k1 + P * P * j);
 #pragma unroll

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, LIB_NAME)   # en
 
 FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
 PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
@@ -34,7 +34,8 @@ class FcDesc(ctypes.Structure):
         ("spatial", ctypes.c_int64 * 3), ("kernel", ctypes.c_int64 * 3), ("stride", ctypes.c_int64 * 3),
         ("padding", ctypes.c_int64 * 3), ("dilation", ctypes.c_int64 * 3),
         ("padding_mode", ctypes.c_int32), ("has_bias", ctypes.c_int32), ("tile_hint", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("transposed", ctypes.c_int32),
+        ("output_padding", ctypes.c_int64 * 3),
     ]
 
 
@@ -101,7 +102,8 @@ class Plan:
     """Owns one ``fc_plan`` (immutable after creation; shareable between threads)."""
 
     def __init__(self, key: Tuple):
-        (ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode, has_bias, tile_hint) = key
+        (ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode, has_bias, tile_hint,
+         transposed, output_padding) = key
         lib = load_library()
         d = FcDesc()
         d.ndim, d.dtype = ndim, 0
@@ -112,7 +114,8 @@ class Plan:
             d.stride[i] = stride[i] if i < ndim else 1
             d.padding[i] = padding[i] if i < ndim else 0
             d.dilation[i] = dilation[i] if i < ndim else 1
-        d.padding_mode, d.has_bias, d.tile_hint = mode, int(has_bias), tile_hint
+            d.output_padding[i] = output_padding[i] if i < ndim else 0
+        d.padding_mode, d.has_bias, d.tile_hint, d.transposed = mode, int(has_bias), tile_hint, int(transposed)
         handle = ctypes.c_void_p()
         st = lib.fc_plan_create(ctypes.byref(d), ctypes.byref(handle))
         if st != FC_OK:

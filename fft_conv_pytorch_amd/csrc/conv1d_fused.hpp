@@ -35,7 +35,8 @@ struct Conv1dArgs {
   int Cig_pad, Cog_pad;  // padded to CIB / COB multiples (spectrum layout)
   int cob;               // out channels per chunk (even)
   int n_ochunks;         // Cog_pad / cob
-  int L, pad, pad_mode;
+  int L, pad, pad_mode;  // source row length, left padding (may be negative for a transposed plan)
+  int up;                // transposed plan: the source is spread over a grid of this step (zeros between)
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
@@ -57,6 +58,14 @@ __device__ __forceinline__ PadMap make_padmap(int mode, int L) {
   m.lo_b = (mode == PAD_CIRCULAR) ? L : 0;
   m.hi_b = (mode == PAD_REFLECT) ? 2 * (L - 1) : (mode == PAD_REPLICATE ? L - 1 : (mode == PAD_CIRCULAR ? -L : 0));
   return m;
+}
+// Zero-spread source of a transposed convolution: grid position pos holds row[pos/up] when pos is a
+// non-negative multiple of up inside the row, zero otherwise (functional.py:126-139).
+__device__ __forceinline__ float load_spread(const float* __restrict__ row, int pos, int L, int up, bool chan_ok) {
+  const int q = pos / up;
+  const bool ok = chan_ok && pos >= 0 && q * up == pos && q < L;
+  const float v = row[ok ? q : 0];
+  return ok ? v : 0.0f;
 }
 __device__ __forceinline__ float load_padded(const float* __restrict__ row, int pos, int L, int pad, const PadMap& m,
                                              bool chan_ok) {
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
 
   const int n_ichunks = a.Cig_pad / CIB;
   const int tile_pos = tile * a.V - a.pad;     // signal coordinate of tile sample 0
-  const bool interior = (tile_pos >= 0) && (tile_pos + T <= a.L);
+  const bool interior = a.up == 1 && (tile_pos >= 0) && (tile_pos + T <= a.L);
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   // buffer descriptors from uniform values only (no waterfall loops)
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
@@ -139,8 +148,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
 #pragma unroll 1
         for (int n1 = 0; n1 < P; ++n1) {
           const int pos = tile_pos + G::N2 * n1 + tseq;
-          col[n1 * G::RS] = mk2(load_padded(r0, pos, a.L, a.pad, pm, has0),
-                                load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1));
+          col[n1 * G::RS] = (a.up == 1)
+                                ? mk2(load_padded(r0, pos, a.L, a.pad, pm, has0),
+                                      load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1))
+                                : mk2(load_spread(r0, pos, a.L, a.up, has0), load_spread(has1 ? r1 : r0, pos, a.L, a.up, has1));
         }
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];

@@ -115,6 +115,7 @@ struct fc_plan {
   const fc::TileImpl* tm;     // middle axis (3-D), full-length FFT
   Twiddles twx, twm;
   int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
+  int padl[3], up[3], ostride[3];   // left pad in grid coordinates, source spread step, output decimation
   int Fx;                     // Tx/2 + 1
   int nd_cob, nd_Cog_pad;
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
@@ -134,8 +135,8 @@ static int plan_1d_persistent(fc_plan* p);
 
 static int plan_1d(fc_plan* p) {
   const fc_desc& d = p->d;
-  const int64_t L = d.spatial[0], pad = d.padding[0], Kd = p->kd[0];
-  const int64_t Lfull = L + 2 * pad - Kd + 1;
+  const int64_t L = d.spatial[0], Kd = p->kd[0];
+  const int64_t Lfull = p->Lf[0];
   p->Lfull = (int)Lfull;
   if (L * (int64_t)std::max(p->Cig, 1) * 4 >= (int64_t)1 << 32)
     return fail(FC_ERR_UNSUPPORTED, "1-D signal too long for 32-bit buffer offsets (Cin/groups * L * 4 must be < 4 GiB)");
@@ -192,7 +193,7 @@ static int plan_1d_persistent(fc_plan* p) {
   const int want = env ? atoi(env) : 0;             // 0 off (default while it does not win), -1 auto, n force nb = n
   if (want == 0) return FC_OK;
   const fc::TileImpl* t = p->tile;
-  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1) return FC_OK;
+  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1 || d.transposed) return FC_OK;
   if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return FC_OK;
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
@@ -238,10 +239,6 @@ static const fc::TileImpl* smallest_tile_at_least(int64_t n) {
 static int plan_nd(fc_plan* p) {
   const fc_desc& d = p->d;
   const int nd = p->nd;
-  for (int i = 0; i < nd; ++i) {
-    p->Sp[i] = (int)(d.spatial[i] + 2 * d.padding[i]);
-    p->Lf[i] = (int)(p->Sp[i] - p->kd[i] + 1);
-  }
   // full-length transforms on the rows axis and (3-D) the middle axis
   p->tx = smallest_tile_at_least(p->Sp[nd - 1]);
   if (!p->tx) return fail(FC_ERR_UNSUPPORTED, "padded extent %d of the last axis exceeds the largest FFT (4096)", p->Sp[nd - 1]);
@@ -330,12 +327,32 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   std::memset(p, 0, sizeof *p);
   p->d = d;
   p->nd = d.ndim;
+  if (d.transposed && d.padding_mode != FC_PAD_CONSTANT) {
+    delete p;
+    return fail(FC_ERR_INVALID, "a transposed plan supports zero padding only");
+  }
   for (int i = 0; i < d.ndim; ++i) {
-    if (d.spatial[i] < 1 || d.kernel[i] < 1 || d.stride[i] < 1 || d.dilation[i] < 1 || d.padding[i] < 0) {
+    if (d.spatial[i] < 1 || d.kernel[i] < 1 || d.stride[i] < 1 || d.dilation[i] < 1 || d.padding[i] < 0 ||
+        (d.transposed && d.output_padding[i] < 0)) {
       delete p;
       return fail(FC_ERR_INVALID, "axis %d: spatial/kernel/stride/dilation must be >= 1 and padding >= 0", i);
     }
     p->kd[i] = (d.kernel[i] - 1) * d.dilation[i] + 1;
+    if (d.transposed) {
+      // functional.py:126-154: spread by the stride, full correlation, keep out samples from `padding`
+      const int64_t out = (d.spatial[i] - 1) * d.stride[i] - 2 * d.padding[i] + p->kd[i] - 1 + d.output_padding[i] + 1;
+      if (out < 1) {
+        delete p;
+        return fail(FC_ERR_INVALID, "axis %d: transposed output extent %lld is not positive", i, (long long)out);
+      }
+      p->out_sp[i] = out;
+      p->padl[i] = (int)(p->kd[i] - 1 - d.padding[i]);
+      p->up[i] = (int)d.stride[i];
+      p->ostride[i] = 1;
+      p->Sp[i] = (int)(out + p->kd[i] - 1);
+      p->Lf[i] = (int)out;
+      continue;
+    }
     const int64_t span = d.spatial[i] + 2 * d.padding[i] - p->kd[i];
     if (span < 0) {
       delete p;
@@ -343,6 +360,11 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
                   (long long)p->kd[i], (long long)(d.spatial[i] + 2 * d.padding[i]));
     }
     p->out_sp[i] = span / d.stride[i] + 1;
+    p->padl[i] = (int)d.padding[i];
+    p->up[i] = 1;
+    p->ostride[i] = (int)d.stride[i];
+    p->Sp[i] = (int)(d.spatial[i] + 2 * d.padding[i]);
+    p->Lf[i] = (int)(span + 1);
     if (d.padding_mode == FC_PAD_REFLECT && d.padding[i] >= d.spatial[i]) {
       delete p;
       return fail(FC_ERR_INVALID, "axis %d: reflect padding (%lld) must be smaller than the input size (%lld)", i,
@@ -414,6 +436,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.G = (int)p.d.groups; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
     a.K = (int)p.d.kernel[0]; a.dil = (int)p.d.dilation[0];
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
+    a.transposed = p.d.transposed;
     const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
     const int grid = (a.nseq + per_wg - 1) / per_wg;
     FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
@@ -433,6 +456,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   r.kz = nd == 3 ? (int)p.d.kernel[0] : 1; r.dz = nd == 3 ? (int)p.d.dilation[0] : 1;
   r.NA = Co * p.Cig; r.NC = nd == 3 ? (int)p.kd[0] : 1; r.NY = (int)p.kd[nd - 2]; r.NYa = r.NY;
   r.SZ = r.kz; r.SY = r.ky; r.SX = r.kx; r.Fx = p.Fx;
+  r.transposed = p.d.transposed; r.Cig = p.Cig; r.Cog = p.Cog;
   FC_HIP(p.tx->rows_r2c(r, st));
   const float norm = 1.0f / ((float)p.tx->T * (float)p.tile->T * (nd == 3 ? (float)p.tm->T : 1.0f));
   fc::C2CArgs c{};
@@ -474,9 +498,9 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.twA = p.tw.twA; a.twB = p.tw.twB;
     a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
-    a.L = (int)p.d.spatial[0]; a.pad = (int)p.d.padding[0]; a.pad_mode = p.d.padding_mode;
+    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0];
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
-    a.stride = (int)p.d.stride[0]; a.accumulate = p.accumulate;
+    a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.stamps = (unsigned long long*)p.debug_stamps;
     a.delay_from = getenv("FFTCONV_DELAY_FROM") ? atoi(getenv("FFTCONV_DELAY_FROM")) : 256;
     a.delay_ticks = getenv("FFTCONV_DELAY_TICKS") ? atoi(getenv("FFTCONV_DELAY_TICKS")) : 0;
@@ -498,11 +522,11 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   fc::f2* wsB = wsA + p.ws_a;
   const int nd = p.nd;
   const int B = (int)p.d.batch, Ci = (int)p.d.in_channels, Co = (int)p.d.out_channels;
-  auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = (int)p.d.padding[ax]; m.mode = p.d.padding_mode; return m; };
+  auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = p.padl[ax]; m.mode = p.d.padding_mode; m.up = p.up[ax]; return m; };
   fc::RowsR2CArgs r{};
   r.src = x; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 0;
   r.mx = amap(nd - 1); r.my = amap(nd - 2); r.mz = amap(0);
-  r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1;
+  r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1; r.transposed = 0; r.Cig = p.Cig; r.Cog = p.Cog;
   r.NA = B * Ci; r.NC = nd == 3 ? p.Sp[0] : 1; r.NY = p.Sp[nd - 2]; r.NYa = r.NY;
   r.SZ = nd == 3 ? (int)p.d.spatial[0] : 1; r.SY = (int)p.d.spatial[nd - 2]; r.SX = (int)p.d.spatial[nd - 1]; r.Fx = p.Fx;
   FC_HIP(p.tx->rows_r2c(r, st));
@@ -512,12 +536,12 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   f.B = B; f.Cin = Ci; f.Cout = Co; f.G = (int)p.d.groups; f.Cig = p.Cig; f.Cog = p.Cog;
   f.Cig_pad = p.Cig_pad; f.Cog_pad = p.nd_Cog_pad; f.cob = p.nd_cob; f.n_ochunks = p.nd_Cog_pad / p.nd_cob;
   f.Kd = (int)p.kd[0]; f.V = p.V; f.ntiles = p.ntiles; f.Lfull = p.Lfull; f.NVo = (int)p.out_sp[0];
-  f.stride = (int)p.d.stride[0]; f.accumulate = p.accumulate; f.NLEN = p.Sp[0];
+  f.stride = p.ostride[0]; f.accumulate = p.accumulate; f.NLEN = p.Sp[0];
 
   fc::RowsC2RArgs o{};
   o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;
   o.NA = B * Co; o.Fx = p.Fx; o.Cout = Co;
-  o.NV = p.Lf[nd - 1]; o.stride = (int)p.d.stride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
+  o.NV = p.Lf[nd - 1]; o.stride = p.ostride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
   o.NY = (int)p.out_sp[nd - 2]; o.NYa = o.NY;
 
   if (nd == 2) {
@@ -541,7 +565,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     c.src = wsA; c.dst = wsB; c.NA = B * Co; c.NC = p.Fx; c.NB = Lzo;
     c.sa = (long long)p.Fx * Ty * Lzo; c.sc = (long long)Ty * Lzo; c.sb = Lzo;
     c.ta = (long long)Lzo * p.Fx * Lyo; c.tb = (long long)p.Fx * Lyo; c.tc = Lyo;
-    c.NV = p.Lf[1]; c.stride = (int)p.d.stride[1];
+    c.NV = p.Lf[1]; c.stride = p.ostride[1];
     FC_HIP(p.tm->c2c_inv(c, st));
     o.src = wsB; o.NC = Lzo;
     FC_HIP(p.tx->rows_c2r(o, st));

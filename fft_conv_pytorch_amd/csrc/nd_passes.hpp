@@ -23,11 +23,16 @@ namespace fc {
 // Index map of one padded axis: position p in [0, n_padded) -> source index or -1 (zero).
 struct AxisMap {
   int size;       // unpadded extent
-  int pad;        // left padding
+  int pad;        // left padding (may be negative for a transposed plan)
   int mode;       // PadMode
+  int up;         // transposed plan: source spread over a grid of this step
 };
 __device__ __forceinline__ int axis_src(const AxisMap& m, int p) {   // p: padded coordinate
   const int pos = p - m.pad;
+  if (m.up > 1) {
+    const int q = pos / m.up;
+    return (pos >= 0 && q * m.up == pos && q < m.size) ? q : -1;
+  }
   if ((unsigned)pos < (unsigned)m.size) return pos;
   if (pos < -m.pad || pos >= m.size + m.pad || m.mode == PAD_CONSTANT) return -1;
   if (m.mode == PAD_REFLECT) return pos < 0 ? -pos : 2 * (m.size - 1) - pos;
@@ -96,6 +101,8 @@ struct RowsR2CArgs {
   const f2* twA;
   const f2* twB;
   int from_kernel;       // 0: signal with padding maps, 1: dilated kernel taps
+  int transposed;        // kernel taps of a transposed plan: (Cin, Cout/g, *k), flipped, in/out swapped per group
+  int Cig, Cog;          // (kernel source only)
   AxisMap mx, my, mz;    // signal: per-axis padding maps (mz unused for 2-D)
   int kx, ky, kz, dx, dy, dz;   // kernel: taps and dilation per axis
   int NA, NC, NY, NYa;   // images, planes per image (padded), rows per plane (padded), row stride of dst
@@ -138,13 +145,20 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
         zs = a.NC > 1 ? axis_src(a.mz, c) : 0;
       }
       ok[h] = ys >= 0 && zs >= 0;
-      rows[h] = a.src + (((size_t)img * a.SZ + (ok[h] ? zs : 0)) * a.SY + (ok[h] ? ys : 0)) * a.SX;
+      size_t simg = img;
+      if (a.from_kernel && a.transposed) {
+        const int o_all = img / a.Cig, i = img % a.Cig;
+        simg = (size_t)((o_all / a.Cog) * a.Cig + i) * a.Cog + (o_all % a.Cog);
+        ys = a.SY - 1 - ys; zs = a.SZ - 1 - zs;
+      }
+      rows[h] = a.src + ((simg * a.SZ + (ok[h] ? zs : 0)) * a.SY + (ok[h] ? ys : 0)) * a.SX;
     }
     f2* col = lds + sq * LSEQP + tseq;
 #pragma unroll 1
     for (int n1 = 0; n1 < P; ++n1) {
       const int xp = G::N2 * n1 + tseq;
-      const int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
+      int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
+      if (a.from_kernel && a.transposed && xs >= 0) xs = a.SX - 1 - xs;
       const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
       const float v1 = (ok[1] && xs >= 0) ? rows[1][xs] : 0.f;
       col[n1 * G::RS] = mk2(v0, v1);

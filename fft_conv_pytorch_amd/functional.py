@@ -38,7 +38,8 @@ class KernelSpectrum:
         self.plan, self.buf, self.workspace = plan, buf, workspace
 
 
-def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=None):
+def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=None,
+              transposed=False, output_padding=0):
     if tile_hint is None:   # debugging / tuning knob: force the FFT tile length
         tile_hint = int(os.environ.get("FFTCONV_TILE", "0"))
     n = signal.ndim - 2
@@ -53,17 +54,30 @@ def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, g
         raise ValueError(f"unknown padding_mode {padding_mode!r}; expected one of constant/zeros/reflect/replicate/circular")
     if not isinstance(groups, int) or groups < 1:
         raise ValueError(f"groups must be a positive int, got {groups!r}")
-    cin, cout = int(signal.shape[1]), int(kernel.shape[0])
-    if cin % groups or cout % groups or int(kernel.shape[1]) * groups != cin:
-        raise ValueError(
-            f"channel mismatch: signal has {cin} channels, kernel is {tuple(kernel.shape)} with groups={groups} "
-            f"(need kernel.shape[1] * groups == in_channels and out_channels % groups == 0)")
+    output_padding_ = to_ntuple(output_padding, n=n)
+    cin = int(signal.shape[1])
+    if transposed:
+        # kernel is (Cin, Cout/groups, *k) as in torch.nn.ConvTranspose{N}d (functional.py:109-114)
+        cout = int(kernel.shape[1]) * groups
+        if cin % groups or int(kernel.shape[0]) != cin:
+            raise ValueError(
+                f"channel mismatch: signal has {cin} channels, transposed kernel is {tuple(kernel.shape)} with "
+                f"groups={groups} (need kernel.shape[0] == in_channels and in_channels % groups == 0)")
+        if padding_mode not in ("constant", "zeros"):
+            raise ValueError("fft_conv_transpose supports zero padding only")
+    else:
+        cout = int(kernel.shape[0])
+        if cin % groups or cout % groups or int(kernel.shape[1]) * groups != cin:
+            raise ValueError(
+                f"channel mismatch: signal has {cin} channels, kernel is {tuple(kernel.shape)} with groups={groups} "
+                f"(need kernel.shape[1] * groups == in_channels and out_channels % groups == 0)")
     if bias is not None and tuple(bias.shape) != (cout,):
         raise ValueError(f"bias must have shape ({cout},), got {tuple(bias.shape)}")
     key = (n, int(signal.shape[0]), cin, cout, groups,
            tuple(int(s) for s in signal.shape[2:]), tuple(int(k) for k in kernel.shape[2:]),
            tuple(int(s) for s in stride_), tuple(int(p) for p in padding_), tuple(int(d) for d in dilation_),
-           _native.PAD_MODES[padding_mode], bias is not None, int(tile_hint))
+           _native.PAD_MODES[padding_mode], bias is not None, int(tile_hint), bool(transposed),
+           tuple(int(o) for o in output_padding_))
     # host-side validation is complete; only now touch the device library
     _require_gpu_f32("signal", signal)
     _require_gpu_f32("kernel", kernel)
@@ -122,10 +136,28 @@ def fft_conv(
     return _forward_native(signal, spectrum, bias)
 
 
-def fft_conv_transpose(*args, **kwargs):
-    raise NotImplementedError(
-        "fft_conv_transpose is outside this round's hot-path scope (SURVEY section 8f, row N2); "
-        "the forward fft_conv / FFTConv{1,2,3}d path is implemented.")
+def fft_conv_transpose(
+    signal: Tensor,
+    kernel: Tensor,
+    bias: Tensor = None,
+    stride: Union[int, Iterable[int]] = 1,
+    padding: Union[int, Iterable[int]] = 0,
+    output_padding: Union[int, Iterable[int]] = 0,
+    dilation: Union[int, Iterable[int]] = 1,
+    groups: int = 1,
+) -> Tensor:
+    """N-d transposed convolution through FFTs, equal to ``torch.nn.functional.conv_transpose{N}d``
+    (reference: functional.py:92-176).
+
+    ``kernel`` is (Cin, Cout/groups, *k).  The same HIP kernels as ``fft_conv`` run it: the stride
+    becomes a zero-spread of the input folded into the load index map, the kernel flip and the
+    in/out channel swap are folded into the kernel transform, padding / output_padding only move
+    the window of kept samples -- no intermediate tensor is materialised.
+    """
+    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, "constant",
+                     transposed=True, output_padding=output_padding)
+    spectrum = transform_kernel(plan, kernel)
+    return _forward_native(signal, spectrum, bias)
 
 
 def complex_matmul(a: Tensor, b: Tensor, groups: int = 1) -> Tensor:

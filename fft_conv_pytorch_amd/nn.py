@@ -32,11 +32,20 @@ class _FFTConvForward(nn.Module):
 
 
 class _FFTConvTransposeForward(nn.Module):
+    """Shared ``forward`` for FFTConvTranspose1d/2d/3d (reference: nn.py:25-39)."""
+
+    cache_kernel_spectrum = True
+
     def forward(self, signal: Tensor):
         assert signal.ndim == self.weight.ndim
-        return F_.fft_conv_transpose(signal, self.weight, bias=self.bias, stride=self.stride,
-                                     padding=self.padding, output_padding=self.output_padding,
-                                     dilation=self.dilation, groups=self.groups)
+        plan = F_._plan_for(signal, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                            self.groups, "constant", transposed=True, output_padding=self.output_padding)
+        tag = (id(plan), self.weight.data_ptr(), self.weight._version)
+        cached = self.__dict__.get("_spectrum_cache")
+        if not self.cache_kernel_spectrum or cached is None or cached[0] != tag:
+            cached = (tag, F_.transform_kernel(plan, self.weight))
+            self.__dict__["_spectrum_cache"] = cached
+        return F_._forward_native(signal, cached[1], self.bias)
 
 
 class FFTConv1d(_FFTConvForward, nn.Conv1d):

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 1
+#define FC_ABI_VERSION 2
 
 enum fc_status {
   FC_OK = 0,
@@ -50,7 +50,10 @@ typedef struct fc_desc {
   int32_t padding_mode;  /* fc_pad_mode; "zeros" of nn.Conv == constant (nn.py:12) */
   int32_t has_bias;
   int32_t tile_hint;     /* 0 = auto; otherwise force the 1-D FFT tile length */
-  int32_t reserved;
+  int32_t transposed;    /* 0: fft_conv (functional.py:19-89); 1: fft_conv_transpose (functional.py:92-176):
+                            kernel is (Cin, Cout/groups, *k), stride spreads the input, padding crops the
+                            output, output_padding extends it; padding_mode must be constant */
+  int64_t output_padding[3];   /* transposed only */
 } fc_desc;
 
 typedef struct fc_plan fc_plan;
@@ -67,7 +70,8 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan);
 void fc_plan_destroy(fc_plan* plan);
 
 /* Output extent per spatial axis: floor((S + 2p - d(k-1) - 1)/stride) + 1,
- * the slice arithmetic of functional.py:76-82 (a9). */
+ * the slice arithmetic of functional.py:76-82 (a9); for a transposed plan
+ * (S-1)*stride - 2p + d(k-1) + output_padding + 1 (functional.py:144-154). */
 int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]);
 
 /* Bytes the caller must provide for the transformed kernel / the scratch area. */

@@ -215,6 +215,59 @@ def fft_conv_oracle_torch(signal, kernel, bias=None, stride=1, padding=0, dilati
     return out.contiguous()
 
 
+# ------------------------------------------------------------- transposed convolution (row N2)
+def transpose_output_extent(size: int, k: int, stride: int, pad: int, dil: int, out_pad: int) -> int:
+    """(s - 1) * stride - 2 p + d (k - 1) + output_padding + 1   (functional.py:144-154)."""
+    return (size - 1) * stride - 2 * pad + dil * (k - 1) + out_pad + 1
+
+
+def fft_conv_transpose_oracle_torch(signal, kernel, bias=None, stride=1, padding=0, output_padding=0,
+                                    dilation=1, groups=1):
+    """Restatement of the reference's transposed convolution (functional.py:92-176) on torch CPU:
+    flip the kernel and swap its in/out channels inside every group (:109-114), zero-stuff it for
+    dilation (:115-124), spread the signal over a zero grid with the stride and a leading offset of
+    K_d - 1 (:126-139), run the forward FFT pipeline on an even extent >= s_ + k - 1 (:143,155-162)
+    and keep output_shape samples starting at the padding (:163-169); bias last (:172-174)."""
+    import torch
+
+    nd = signal.dim() - 2
+    pad = ntuple(padding, nd)
+    opad = ntuple(output_padding, nd)
+    strd = ntuple(stride, nd)
+    dil = ntuple(dilation, nd)
+    axes = tuple(range(2, 2 + nd))
+    cin, cog = kernel.shape[:2]
+
+    w = torch.flip(kernel, dims=axes)                                   # spatial flip
+    w = w.reshape(groups, cin // groups, cog, *kernel.shape[2:]).transpose(1, 2)
+    w = w.reshape(groups * cog, cin // groups, *kernel.shape[2:])        # (Cout, Cin/g, *k)
+    if any(d != 1 for d in dil):
+        wide = [(k - 1) * d + 1 for k, d in zip(w.shape[2:], dil)]
+        stuffed = torch.zeros(tuple(w.shape[:2]) + tuple(wide), dtype=w.dtype)
+        stuffed[(Ellipsis,) + tuple(slice(None, None, d) for d in dil)] = w
+        w = stuffed
+    kd = w.shape[2:]
+    grid = [(s - 1) * t + 1 + (k - 1) for s, k, t in zip(signal.shape[2:], kd, strd)]
+    spread = torch.zeros(tuple(signal.shape[:2]) + tuple(grid), dtype=signal.dtype)
+    spread[(Ellipsis,) + tuple(slice(k - 1, None, t) for k, t in zip(kd, strd))] = signal
+    extent = [(s + k) // 2 * 2 for s, k in zip(grid, kd)]
+    out_shape = [transpose_output_extent(s, k, t, p, d, o)
+                 for s, k, t, p, d, o in zip(signal.shape[2:], kernel.shape[2:], strd, pad, dil, opad)]
+
+    sig_f = torch.fft.rfftn(spread, s=extent, dim=axes)
+    ker_f = torch.fft.rfftn(w, s=extent, dim=axes).conj()
+    b = signal.shape[0]
+    sig_g = sig_f.reshape(b, groups, cin // groups, *sig_f.shape[2:])
+    ker_g = ker_f.reshape(groups, cog, cin // groups, *ker_f.shape[2:])
+    prod = torch.einsum("bgi...,goi...->bgo...", sig_g, ker_g).reshape(b, groups * cog, *sig_f.shape[2:])
+    full = torch.fft.irfftn(prod, s=extent, dim=axes)
+    window = (slice(None), slice(None)) + tuple(slice(p, p + n) for p, n in zip(pad, out_shape))
+    out = full[window]
+    if bias is not None:
+        out = out + bias.reshape(1, -1, *([1] * nd))
+    return out.contiguous()
+
+
 def rel_err(y, y_ref) -> float:
     """max|y - y_ref| / max|y_ref| -- the parity measure of BASELINE.md section 3."""
     y = np.asarray(y, dtype=np.float64)

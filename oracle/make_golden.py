@@ -51,6 +51,37 @@ def make_inputs(seed, batch, cin, cout, groups, spatial, ksize):
     return x, w, b
 
 
+def run_ref_transpose(ref, x, w, b, **kw):
+    import torch
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = ref.functional.fft_conv_transpose(torch.from_numpy(x), torch.from_numpy(w),
+                                              bias=None if b is None else torch.from_numpy(b), **kw)
+    return y.contiguous().numpy()
+
+
+def g4_cases():
+    """Transposed convolution: thinned copy of the reference grid (tests/test_functional_transpose.py:11-21,
+    including its `dilation += output_padding; stride += output_padding` adjustment) plus longer rows."""
+    grid = itertools.product([1, 2, 3], [7, 8], [2, 3], [2, 3], [1, 2, 3], [2, 3], [0, 1], [1, 2], [1, 2], [0, 1, 2])
+    cases = []
+    for idx, (nd, size, cin, cout, groups, k, pad, stride, dil, opad) in enumerate(grid):
+        g = int(np.gcd(cin, np.gcd(cout, groups)))
+        keep = (idx % 17 == 0) if nd == 1 else ((idx % 61 == 0) if nd == 2 else (idx % 331 == 0))
+        if not keep:
+            continue
+        cases.append(dict(batch=2, cin=cin, cout=cout, groups=g, spatial=(size,) * nd, k=(k,) * nd, padding=pad,
+                          stride=stride + opad, dilation=dil + opad, output_padding=opad))
+    cases += [
+        dict(batch=2, cin=8, cout=8, groups=1, spatial=(3000,), k=(129,), padding=64, stride=1, dilation=1, output_padding=0),
+        dict(batch=1, cin=8, cout=16, groups=2, spatial=(1000,), k=(33,), padding=5, stride=3, dilation=2, output_padding=2),
+        dict(batch=2, cin=6, cout=4, groups=2, spatial=(40, 37), k=(5, 4), padding=(2, 1), stride=(2, 1), dilation=(1, 2), output_padding=(1, 0)),
+        dict(batch=1, cin=4, cout=6, groups=1, spatial=(9, 10, 8), k=(3, 2, 3), padding=(1, 0, 2), stride=(2, 1, 2), dilation=1, output_padding=(1, 0, 1)),
+        dict(batch=2, cin=3, cout=5, groups=1, spatial=(50,), k=(4,), padding=7, stride=2, dilation=3, output_padding=1),
+    ]
+    return cases
+
+
 def run_ref(ref, x, w, b, **kw):
     import torch
     with warnings.catch_warnings():
@@ -107,9 +138,30 @@ BASELINE_CONFIGS = {
 }
 
 
+def make_g4(ref):
+    store = {}
+    cases = g4_cases()
+    for n, c in enumerate(cases):
+        seed = 7000 + 3 * n
+        x = seeded(seed, c["batch"], c["cin"], *c["spatial"])
+        w = seeded(seed + 1, c["cin"], c["cout"] // c["groups"], *c["k"])      # transposed layout (Cin, Cout/g, *k)
+        b = seeded(seed + 2, c["cout"])
+        y = run_ref_transpose(ref, x, w, b, stride=c["stride"], padding=c["padding"],
+                              output_padding=c["output_padding"], dilation=c["dilation"], groups=c["groups"])
+        store[f"x{n}"], store[f"w{n}"], store[f"b{n}"], store[f"y{n}"] = x, w, b, y
+        store[f"meta{n}"] = np.array(repr(c))
+    store["count"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT_DIR, "g4_transpose.npz"), **store)
+    print("G4:", len(cases), "cases")
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     ref = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "g4":
+        make_g4(ref)
+        return
+    make_g4(ref)
 
     # ---- G1
     store = {}

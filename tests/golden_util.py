@@ -43,6 +43,15 @@ def g2_cases():
             yield n, z[f"x{n}"], z[f"w{n}"], z[f"b{n}"], kw, z[f"y{n}"]
 
 
+def g4_cases():
+    z = np.load(os.path.join(GOLDEN, "g4_transpose.npz"))
+    for n in range(int(z["count"])):
+        meta = ast.literal_eval(str(z[f"meta{n}"]))
+        kw = dict(stride=meta["stride"], padding=meta["padding"], output_padding=meta["output_padding"],
+                  dilation=meta["dilation"], groups=meta["groups"])
+        yield n, z[f"x{n}"], z[f"w{n}"], z[f"b{n}"], kw, z[f"y{n}"]
+
+
 BASELINE_CONFIGS = {
     "cfg0": (1, 8, 8, 1, (32768,), (128,), 1),
     "cfgA": (32, 8, 8, 1, (32768,), (512,), 1),

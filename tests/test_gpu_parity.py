@@ -185,3 +185,68 @@ def test_module_matches_functional_and_tracks_weight_updates():
     assert set(sd) == {"weight", "bias"}
     with pytest.raises(AssertionError):
         layer(x[0])                     # unbatched input is rejected like the reference (nn.py:11)
+
+
+# ----------------------------------------------------------------------------- transposed convolution (row N2)
+def _hip_t(x, w, b, **kw):
+    from fft_conv_pytorch_amd.functional import fft_conv_transpose
+    t = lambda a: None if a is None else torch.as_tensor(a).to(DEV)
+    y = fft_conv_transpose(t(x), t(w), bias=t(b), **kw)
+    torch.cuda.synchronize()
+    return y.cpu().numpy()
+
+
+def test_transpose_golden_g4():
+    worst, count = 0.0, 0
+    for n, x, w, b, kw, y_ref in gu.g4_cases():
+        worst = max(worst, gu.check_against(_hip_t(x, w, b, **kw), y_ref, REL_TOL))
+        count += 1
+    print(f"G4: {count} transposed cases, worst rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3])
+def test_transpose_reference_grid_against_torch_direct(ndim):
+    """The reference's transposed grid (tests/test_functional_transpose.py:11-21, with its
+    `dilation += output_padding; stride += output_padding` rule), seeded, against torch's
+    conv_transpose on the CPU with the reference's absolute tolerance."""
+    from fft_conv_pytorch_amd.functional import fft_conv_transpose
+    gen = torch.Generator().manual_seed(4321 + ndim)
+    conv = getattr(F, f"conv_transpose{ndim}d")
+    grid = itertools.product([2, 3], [2, 3], [1, 2, 3], [2, 3], [0, 1], [1, 2], [1, 2], [0, 1, 2], [7, 8])
+    count = 0
+    for cin, cout, groups, k, pad, stride, dil, opad, size in grid:
+        g = _gcd3(cin, cout, groups)
+        if ndim == 3 and (count % 3):      # thin the 3-D sweep (same coverage of every axis value)
+            count += 1
+            continue
+        x = torch.randn(2, cin, *([size] * ndim), generator=gen)
+        w = torch.randn(cin, cout // g, *([k] * ndim), generator=gen)
+        b = torch.randn(cout, generator=gen)
+        kw = dict(stride=stride + opad, padding=pad, output_padding=opad, dilation=dil + opad, groups=g)
+        y = fft_conv_transpose(x.to(DEV), w.to(DEV), bias=b.to(DEV), **kw).cpu()
+        y_ref = conv(x, w, bias=b, **kw)
+        assert y.shape == y_ref.shape
+        err = (y - y_ref).abs()
+        assert err.max().item() < 1e-4 and err.mean().item() < 5e-5, (cin, cout, g, k, pad, stride, dil, opad, size)
+        count += 1
+    assert count == 1152
+
+
+def test_transpose_module_and_long_rows():
+    from fft_conv_pytorch_amd import FFTConvTranspose1d, FFTConvTranspose2d
+    torch.manual_seed(1)
+    layer = FFTConvTranspose1d(8, 8, 129, stride=2, padding=10, output_padding=1).to(DEV)
+    x = torch.randn(2, 8, 5000, device=DEV)
+    y = layer(x)
+    ref = F.conv_transpose1d(x.cpu(), layer.weight.detach().cpu(), layer.bias.detach().cpu(), stride=2, padding=10,
+                             output_padding=1)
+    assert y.shape == ref.shape
+    assert (y.cpu() - ref).abs().max().item() / ref.abs().max().item() < REL_TOL
+    layer2 = FFTConvTranspose2d(4, 6, (5, 3), stride=(2, 3), padding=(2, 1), groups=2).to(DEV)
+    x2 = torch.randn(2, 4, 33, 40, device=DEV)
+    y2 = layer2(x2)
+    ref2 = F.conv_transpose2d(x2.cpu(), layer2.weight.detach().cpu(), layer2.bias.detach().cpu(), stride=(2, 3),
+                              padding=(2, 1), groups=2)
+    assert y2.shape == ref2.shape
+    assert (y2.cpu() - ref2).abs().max().item() / ref2.abs().max().item() < REL_TOL
+    assert set(layer2.state_dict()) == {"weight", "bias"}

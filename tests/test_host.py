@@ -44,7 +44,7 @@ def test_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     assert lib.fc_version() == _native.ABI_VERSION
-    assert ctypes.sizeof(_native.FcDesc) == 8 + 4 * 8 + 5 * 24 + 16
+    assert ctypes.sizeof(_native.FcDesc) == 8 + 4 * 8 + 5 * 24 + 16 + 24
 
 
 def test_host_validation_happens_before_any_device_call():

@@ -65,3 +65,18 @@ def test_output_extent_formula():
     for size, k, s, p, d in [(7, 2, 1, 0, 1), (8, 3, 2, 1, 2), (32768, 512, 1, 0, 1), (100, 7, 3, 5, 2)]:
         y = torch.nn.functional.conv1d(torch.zeros(1, 1, size), torch.zeros(1, 1, k), stride=s, padding=p, dilation=d)
         assert orc.output_extent(size, k, s, p, d) == y.shape[-1]
+
+
+def test_transpose_oracle_matches_reference_g4():
+    """Row N2: the transposed-convolution restatement against the real reference's outputs and against
+    torch's direct conv_transpose (the ground truth of tests/test_functional_transpose.py:62-66)."""
+    import torch.nn.functional as F
+    count = 0
+    for n, x, w, b, kw, y_ref in gu.g4_cases():
+        xt, wt, bt = torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b)
+        y = orc.fft_conv_transpose_oracle_torch(xt, wt, bt, **kw).numpy()
+        gu.check_against(y, y_ref, TIGHT)
+        y_direct = getattr(F, f"conv_transpose{x.ndim - 2}d")(xt, wt, bt, **kw).numpy()
+        gu.check_against(y_direct, y_ref, TIGHT)
+        count += 1
+    assert count > 40

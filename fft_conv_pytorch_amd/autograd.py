@@ -1,0 +1,124 @@
+"""Backward of ``fft_conv`` built from the same HIP kernels.
+
+The reference has no custom backward: autograd differentiates its rfftn/einsum/irfftn graph
+(/root/reference/tests/test_functional.py:111-117 pins dW and db).  A C-ABI forward is opaque to
+autograd, so the three gradients are expressed as convolutions the native library already runs:
+
+    dX = conv_transpose(dY, W)             -> ``fc_forward`` on a transposed plan
+    dW = correlate(X, dY) over the batch   -> ``fc_forward`` with the roles of batch and channels
+                                              swapped: signal' = X^T (Cin/g, B, *S), kernel' = dY^T
+                                              (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;
+                                              long 1-D rows are cut into chunks that ride the group axis
+    db = sum of dY over batch and space    -> a plain reduction
+
+torch is used for data movement only (transposes, unfold views, the final chunk sum and db).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import functional as F_
+
+_MAX_KERNEL_EXTENT = 2048      # dilated extent of kernel' that still leaves a useful valid window in a 4096 tile
+
+
+def _grad_input(grad: Tensor, weight: Tensor, in_spatial, stride, padding, dilation, groups, padding_mode) -> Tensor:
+    n = grad.ndim - 2
+    pad_t = padding if padding_mode == "constant" else (0,) * n
+    full = tuple(s + 2 * (p if padding_mode != "constant" else 0) for s, p in zip(in_spatial, padding))
+    out_pad = []
+    for i in range(n):
+        base = (grad.shape[2 + i] - 1) * stride[i] - 2 * pad_t[i] + dilation[i] * (weight.shape[2 + i] - 1) + 1
+        out_pad.append(full[i] - base)
+    # conv weight (Cout, Cin/g, *k) is exactly the transposed-conv layout (Cin_t = Cout, Cout_t/g = Cin/g)
+    dx = F_.fft_conv_transpose(grad, weight, None, stride=stride, padding=pad_t, output_padding=tuple(out_pad),
+                               dilation=dilation, groups=groups)
+    if padding_mode == "constant":
+        return dx
+    # adjoint of the non-zero padding: let torch back-propagate through its own pad (data movement)
+    flat = []
+    for p in reversed(padding):
+        flat += [p, p]
+    with torch.enable_grad():       # backward() runs with grad mode off
+        probe = torch.zeros((dx.shape[0], dx.shape[1]) + tuple(in_spatial), device=dx.device, dtype=dx.dtype,
+                            requires_grad=True)
+        padded = F.pad(probe, flat, mode=padding_mode)
+    return torch.autograd.grad(padded, probe, dx)[0]
+
+
+def _grad_weight_group(x: Tensor, grad: Tensor, ksize, stride, padding, dilation, padding_mode) -> Tensor:
+    """dW of one channel group.  x: (B, Ci, *S), grad: (B, Co, *Lout) -> (Co, Ci, *k)."""
+    n = x.ndim - 2
+    b = x.shape[0]
+    xt = x.transpose(0, 1).contiguous()          # (Ci, B, *S)   : batch' = Ci, channels' = B
+    gt = grad.transpose(0, 1).contiguous()       # (Co, B, *Lout): out' = Co,  in' = B
+    kext = [(grad.shape[2 + i] - 1) * stride[i] + 1 for i in range(n)]
+    if n == 1 and kext[0] > _MAX_KERNEL_EXTENT:
+        # Long rows: kernel' (the gradient) is cut into chunks of C taps; chunk j only meets the signal
+        # window [j*C*s - p, j*C*s - p + (C-1)*s + 1 + Kd - 1).  Chunks ride the group axis.
+        s, p, d = stride[0], padding[0], dilation[0]
+        kd = (ksize[0] - 1) * d + 1
+        c_taps = max(1, (_MAX_KERNEL_EXTENT - 1) // s + 1)
+        lout = grad.shape[2]
+        nchunk = (lout + c_taps - 1) // c_taps
+        seg = (c_taps - 1) * s + kd                                  # signal samples one chunk needs
+        flat = [p, p] if p else None
+        xp = F.pad(xt, flat, mode=padding_mode) if flat else xt      # (Ci, B, S+2p)
+        need = (nchunk - 1) * c_taps * s + seg
+        if xp.shape[-1] < need:
+            xp = F.pad(xp, [0, need - xp.shape[-1]])
+        win = xp.unfold(-1, seg, c_taps * s)[:, :, :nchunk]          # (Ci, B, nchunk, seg)
+        sig = win.permute(0, 2, 1, 3).reshape(xt.shape[0], nchunk * b, seg).contiguous()
+        gpad = F.pad(gt, [0, nchunk * c_taps - lout])                # (Co, B, nchunk*C)
+        ker = gpad.reshape(gt.shape[0], b, nchunk, c_taps).permute(2, 0, 1, 3).reshape(nchunk * gt.shape[0], b, c_taps)
+        part = F_.fft_conv(sig, ker.contiguous(), None, stride=d, padding=0, dilation=s, groups=nchunk)
+        part = part.reshape(xt.shape[0], nchunk, gt.shape[0], -1).sum(dim=1)      # (Ci, Co, >=k)
+        return part[..., : ksize[0]].permute(1, 0, 2).contiguous()
+    out = F_.fft_conv(xt, gt, None, stride=dilation, padding=padding, dilation=stride, groups=1,
+                      padding_mode=padding_mode)                    # (Ci, Co, >= k per axis)
+    index = (slice(None), slice(None)) + tuple(slice(0, k) for k in ksize)
+    return out[index].transpose(0, 1).contiguous()
+
+
+def _grad_weight(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
+    cout, cig = wshape[0], wshape[1]
+    cog = cout // groups
+    parts = []
+    for g in range(groups):
+        parts.append(_grad_weight_group(x[:, g * cig:(g + 1) * cig], grad[:, g * cog:(g + 1) * cog],
+                                        tuple(wshape[2:]), stride, padding, dilation, padding_mode))
+    return parts[0] if groups == 1 else torch.cat(parts, dim=0)
+
+
+class FFTConvFunction(torch.autograd.Function):
+    """``fft_conv`` with gradients; ``spectrum`` is an optional pre-transformed kernel (module cache)."""
+
+    @staticmethod
+    def forward(ctx, signal: Tensor, kernel: Tensor, bias: Optional[Tensor], stride: Tuple[int, ...],
+                padding: Tuple[int, ...], dilation: Tuple[int, ...], groups: int, padding_mode: str, spectrum):
+        plan = F_._plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode)
+        if spectrum is None or spectrum.plan is not plan:
+            spectrum = F_.transform_kernel(plan, kernel)
+        ctx.save_for_backward(signal, kernel)
+        ctx.conf = (stride, padding, dilation, groups, padding_mode, bias is not None)
+        return F_._forward_native(signal, spectrum, bias)
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        signal, kernel = ctx.saved_tensors
+        stride, padding, dilation, groups, padding_mode, has_bias = ctx.conf
+        grad = grad.contiguous()
+        d_signal = d_kernel = d_bias = None
+        if ctx.needs_input_grad[0]:
+            d_signal = _grad_input(grad, kernel.detach(), tuple(signal.shape[2:]), stride, padding, dilation, groups,
+                                   padding_mode)
+        if ctx.needs_input_grad[1]:
+            d_kernel = _grad_weight(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation, groups,
+                                    padding_mode)
+        if has_bias and ctx.needs_input_grad[2]:
+            d_bias = grad.sum(dim=[0] + list(range(2, grad.ndim)))
+        return d_signal, d_kernel, d_bias, None, None, None, None, None, None

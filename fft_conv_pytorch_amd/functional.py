@@ -131,8 +131,23 @@ def fft_conv(
     input raises ``ValueError`` (torch's behaviour) instead of returning a
     wrongly shaped tensor.
     """
+    return _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, None)
+
+
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
+def _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, spectrum):
+    """Shared by the functional and the modules; ``spectrum`` is an optional cached kernel transform."""
+    if _needs_grad(signal, kernel, bias):
+        from .autograd import FFTConvFunction        # backward built from the same kernels (row N1)
+        n = signal.ndim - 2
+        return FFTConvFunction.apply(signal, kernel, bias, to_ntuple(stride, n), to_ntuple(padding, n),
+                                     to_ntuple(dilation, n), groups, padding_mode, spectrum)
     plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode)
-    spectrum = transform_kernel(plan, kernel)     # the reference also re-transforms per call (functional.py:71)
+    if spectrum is None or spectrum.plan is not plan:
+        spectrum = transform_kernel(plan, kernel)   # the reference also re-transforms per call (functional.py:71)
     return _forward_native(signal, spectrum, bias)
 
 

@@ -28,7 +28,8 @@ class _FFTConvForward(nn.Module):
         if not self.cache_kernel_spectrum or cached is None or cached[0] != tag:
             cached = (tag, F_.transform_kernel(plan, self.weight))
             self.__dict__["_spectrum_cache"] = cached
-        return F_._forward_native(signal, cached[1], self.bias)
+        return F_._fft_conv_impl(signal, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                                 self.groups, padding_mode, cached[1])
 
 
 class _FFTConvTransposeForward(nn.Module):

@@ -250,3 +250,46 @@ def test_transpose_module_and_long_rows():
     assert y2.shape == ref2.shape
     assert (y2.cpu() - ref2).abs().max().item() / ref2.abs().max().item() < REL_TOL
     assert set(layer2.state_dict()) == {"weight", "bias"}
+
+
+# ----------------------------------------------------------------------------- backward (row N1)
+@pytest.mark.parametrize("ndim", [1, 2, 3])
+def test_backward_reference_grid(ndim):
+    """dW and db as the reference pins them (tests/test_functional.py:62-117), plus dX, against torch's
+    direct convolution on the CPU, over the reference's grid (thinned for 2-D/3-D)."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(99 + ndim)
+    conv = getattr(F, f"conv{ndim}d")
+    grid = list(itertools.product([2, 3], [2, 3], [1, 2, 3], [2, 3], [0, 1], [1, 2], [1, 2], [7, 8]))
+    step = {1: 1, 2: 3, 3: 11}[ndim]
+    for cin, cout, groups, k, pad, stride, dil, size in grid[::step]:
+        g = _gcd3(cin, cout, groups)
+        x = torch.randn(2, cin, *([size] * ndim), generator=gen)
+        w = torch.randn(cout, cin // g, *([k] * ndim), generator=gen)
+        b = torch.randn(cout, generator=gen)
+        kw = dict(stride=stride, padding=pad, dilation=dil, groups=g)
+        xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+        xc, wc, bc = (t.clone().requires_grad_() for t in (x, w, b))
+        fft_conv(xd, wd, bias=bd, **kw).sum().backward()
+        conv(xc, wc, bias=bc, **kw).sum().backward()
+        for got, ref in ((xd.grad, xc.grad), (wd.grad, wc.grad), (bd.grad, bc.grad)):
+            err = (got.cpu() - ref).abs()
+            assert err.max().item() < 1e-4 * max(1.0, ref.abs().max().item()), (cin, cout, g, k, pad, stride, dil, size)
+
+
+@pytest.mark.parametrize("mode", ["constant", "reflect", "replicate", "circular"])
+def test_backward_long_rows_and_padding_modes(mode):
+    """Chunked dW path (gradient longer than one tile), multi-channel groups, every padding mode."""
+    from fft_conv_pytorch_amd import FFTConv1d
+    torch.manual_seed(5)
+    layer = FFTConv1d(8, 12, 65, stride=2, padding=20, dilation=2, groups=4, padding_mode="zeros" if mode == "constant" else mode).to(DEV)
+    ref = torch.nn.Conv1d(8, 12, 65, stride=2, padding=20, dilation=2, groups=4, padding_mode="zeros" if mode == "constant" else mode)
+    ref.load_state_dict({k: v.cpu() for k, v in layer.state_dict().items()})
+    x = torch.randn(3, 8, 9000)
+    xd = x.to(DEV).requires_grad_()
+    xc = x.clone().requires_grad_()
+    gy = torch.randn_like(ref(xc))
+    layer(xd).backward(gy.to(DEV))
+    ref(xc).backward(gy)
+    for got, want in ((xd.grad, xc.grad), (layer.weight.grad, ref.weight.grad), (layer.bias.grad, ref.bias.grad)):
+        assert (got.cpu() - want).abs().max().item() / want.abs().max().item() < REL_TOL

@@ -58,7 +58,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   __syncthreads();
 
-  for (int it = blockIdx.x; it < pa.n_items; it += gridDim.x) {
+  // one work item per workgroup: a resident loop over items made hipcc hoist per-item invariants
+  // across the whole kernel and spill the FFT registers around every barrier
+  {
+    const int it = blockIdx.x;
     const WorkItem wi = pa.items[it];
     const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
     const int tile = wi.tile;

@@ -210,17 +210,35 @@ static int plan_1d_persistent(fc_plan* p) {
   if (nb == 0) return FC_OK;
   int slot = nb == t->pers_nb[0] ? 0 : 1;
   const int wgs_per_cu = std::max(1, (int)((160 * 1024) / t->pers_lds[slot]));
+  // Items: up to nb batch items that share (tile, group, out-chunk), full items first.  When the last
+  // residency round would fill less than half of the CUs, its items are split in two so the tail
+  // spreads over twice as many CUs (cfgA: 336 pairs on 256 CUs -> 256 pairs + 160 singles).
   std::vector<fc::WorkItem> items;
   const int nfull = (int)(B / nb), rem = (int)(B % nb);
-  for (int pass = 0; pass < 2; ++pass)              // full items first, remainders last
-    for (int tile = 0; tile < p->ntiles; ++tile)
-      for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) {
-        if (pass == 0) for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
-        else if (rem) items.push_back({nfull * nb, rem, tile, goc});
+  const int64_t slots = (int64_t)cus * wgs_per_cu;
+  for (int tile = 0; tile < p->ntiles; ++tile)
+    for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
+      for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
+  if (nb >= 2 && (int64_t)items.size() > slots) {
+    const int64_t tail = (int64_t)items.size() % slots;
+    if (tail > 0 && tail <= slots / 2) {
+      std::vector<fc::WorkItem> split;
+      for (int64_t k = (int64_t)items.size() - tail; k < (int64_t)items.size(); ++k) {
+        const fc::WorkItem w = items[k];
+        const int h = w.nbc / 2;
+        split.push_back({w.b0, h, w.tile, w.goc});
+        split.push_back({w.b0 + h, w.nbc - h, w.tile, w.goc});
       }
+      items.resize(items.size() - tail);
+      items.insert(items.end(), split.begin(), split.end());
+    }
+  }
+  if (rem)
+    for (int tile = 0; tile < p->ntiles; ++tile)
+      for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) items.push_back({nfull * nb, rem, tile, goc});
   if (items.size() > 0x7fffffffu) return FC_OK;
   p->pers_items = (int)items.size();
-  p->pers_grid = (int)std::min<int64_t>(p->pers_items, (int64_t)cus * wgs_per_cu);
+  p->pers_grid = p->pers_items;      // one item per workgroup
   FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
   FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;

@@ -121,6 +121,7 @@ struct fc_plan {
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
+  int pers_nb_choice;         // planner's pick for this plan (0 = general kernel)
   int pers_grid, pers_items;
   fc::WorkItem* d_items;
 };
@@ -132,6 +133,7 @@ int fc_version(void) { return FC_ABI_VERSION; }
 const char* fc_last_error(void) { return g_err.c_str(); }
 
 static int plan_1d_persistent(fc_plan* p);
+static int choose_fast_path(fc_plan* p, int* tile_out);
 
 static int plan_1d(fc_plan* p) {
   const fc_desc& d = p->d;
@@ -147,9 +149,15 @@ static int plan_1d(fc_plan* p) {
   double best_cost = 0;
   int ntl;
   auto tiles = all_tiles(&ntl);
+  int forced_tile = d.tile_hint;
+  p->pers_nb_choice = 0;
+  if (!forced_tile) {
+    int rc = choose_fast_path(p, &forced_tile);
+    if (rc != FC_OK) return rc;
+  }
   for (int i = 0; i < ntl; ++i) {
     const fc::TileImpl* t = tiles[i];
-    if (d.tile_hint && t->T != d.tile_hint) continue;
+    if (forced_tile && t->T != forced_tile) continue;
     if (t->T < Kd) continue;
     const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
     if (lds > lds_cap) continue;
@@ -184,29 +192,67 @@ static int plan_1d(fc_plan* p) {
 }
 
 
+static bool fast_path_eligible(const fc_plan* p) {
+  const fc_desc& d = p->d;
+  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1 || d.transposed) return false;
+  if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return false;
+  return true;
+}
+
+// Joint choice of FFT tile and kernel flavour for 8-channel chunks.  Measured per-workgroup times on
+// MI355X (us, phase_profile.py, cfgA-like rows): the general kernel at 2048 / 1024 and the
+// batch-sharing kernel at (2048, nb 2), (1024, nb 2), (1024, nb 4); estimated launch time =
+// residency rounds x time per workgroup.  Small problems are decided by the rounds, large ones by
+// outputs per microsecond.
+static int choose_fast_path(fc_plan* p, int* tile_out) {
+  const fc_desc& d = p->d;
+  const char* env = getenv("FFTCONV_PERS");
+  const int want = env ? atoi(env) : -1;            // -1 auto, 0 general kernel only, n force nb = n
+  if (want == 0 || !fast_path_eligible(p)) return FC_OK;
+  int dev = 0, cus = 256;
+  FC_HIP(hipGetDevice(&dev));
+  FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  const int64_t Kd = p->kd[0], Lfull = p->Lf[0], B = d.batch;
+  const int64_t per_item_units = (int64_t)p->n_ochunks * d.groups;
+  struct Cand { int T, nb, wgs_per_cu; double t_item; };
+  const Cand cands[] = {{2048, 0, 2, 26.4}, {1024, 0, 4, 29.0}, {2048, 2, 1, 20.1}, {1024, 2, 2, 14.7}, {1024, 4, 1, 16.8}};
+  double best = 0;
+  int best_T = 0, best_nb = 0;
+  for (const Cand& c : cands) {
+    if (c.T < Kd) continue;
+    if (want > 0 && c.nb != want) continue;
+    if (c.nb > B && c.nb != 0) continue;
+    const int64_t V = c.T - Kd + 1;
+    const int64_t nt = (Lfull + V - 1) / V;
+    const int64_t items = ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt * per_item_units;
+    const int64_t slots = (int64_t)cus * c.wgs_per_cu;
+    const double est = (double)((items + slots - 1) / slots) * c.t_item;
+    if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; }
+  }
+  if (best_T == 0) return FC_OK;                    // kernel too long for these tiles: general planner decides
+  if (want > 0 && best_nb == 0) return FC_OK;
+  *tile_out = best_T;
+  p->pers_nb_choice = best_nb;
+  return FC_OK;
+}
+
 // Work list of the persistent fused kernel: items of up to NB batch items that share (tile, group,
 // out-chunk), largest first; workgroup w takes items w, w+grid, ...  One workgroup per LDS slot.
 static int plan_1d_persistent(fc_plan* p) {
   p->pers_nb = 0; p->d_items = nullptr; p->pers_items = 0; p->pers_grid = 0;
   const fc_desc& d = p->d;
-  const char* env = getenv("FFTCONV_PERS");
-  const int want = env ? atoi(env) : 0;             // 0 off (default while it does not win), -1 auto, n force nb = n
-  if (want == 0) return FC_OK;
+  if (!fast_path_eligible(p)) return FC_OK;
   const fc::TileImpl* t = p->tile;
-  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1 || d.transposed) return FC_OK;
-  if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return FC_OK;
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int64_t B = d.batch, units = (int64_t)p->ntiles * p->n_ochunks * d.groups;   // per batch item
-  int nb = 0;
-  for (int k = 0; k < 2; ++k) {
-    const int cand = t->pers_nb[k];
-    if (!cand) continue;
-    if (want > 0) { if (cand == want) nb = cand; continue; }
-    // prefer the largest sharing factor that still leaves every CU a workgroup
-    if (cand <= B && (nb == 0 || units * ((B + cand - 1) / cand) >= cus)) nb = cand;
+  const int64_t B = d.batch;
+  int nb = p->pers_nb_choice;
+  if (d.tile_hint) {                                // explicit tile: FFTCONV_PERS picks the flavour (default general)
+    const char* env = getenv("FFTCONV_PERS");
+    nb = env ? atoi(env) : 0;
   }
+  if (nb != t->pers_nb[0] && nb != t->pers_nb[1]) nb = 0;
   if (nb == 0) return FC_OK;
   int slot = nb == t->pers_nb[0] ? 0 : 1;
   const int wgs_per_cu = std::max(1, (int)((160 * 1024) / t->pers_lds[slot]));

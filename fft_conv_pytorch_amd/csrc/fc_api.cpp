@@ -208,29 +208,31 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   const fc_desc& d = p->d;
   const char* env = getenv("FFTCONV_PERS");
   const int want = env ? atoi(env) : -1;            // -1 auto, 0 general kernel only, n force nb = n
-  if (want == 0 || !fast_path_eligible(p)) return FC_OK;
+  const bool fast_ok = want != 0 && fast_path_eligible(p);
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t Kd = p->kd[0], Lfull = p->Lf[0], B = d.batch;
   const int64_t per_item_units = (int64_t)p->n_ochunks * d.groups;
+  // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
-  const Cand cands[] = {{2048, 0, 2, 26.4}, {1024, 0, 4, 29.0}, {2048, 2, 1, 20.1}, {1024, 2, 2, 14.7}, {1024, 4, 1, 16.8}};
+  const Cand cands[] = {{256, 0, 8, 10.9}, {512, 0, 6, 10.4}, {1024, 0, 4, 24.0}, {2048, 0, 2, 26.4},
+                        {2048, 2, 1, 20.1}, {1024, 2, 2, 14.7}, {1024, 4, 1, 16.8}};
   double best = 0;
   int best_T = 0, best_nb = 0;
   for (const Cand& c : cands) {
-    if (c.T < Kd) continue;
+    if (c.T < Kd || p->accumulate) continue;
+    if (c.nb != 0 && (!fast_ok || c.nb > B)) continue;
     if (want > 0 && c.nb != want) continue;
-    if (c.nb > B && c.nb != 0) continue;
     const int64_t V = c.T - Kd + 1;
+    if (V * 4 < c.T) continue;                      // less than a quarter of the tile useful: leave to the cost model
     const int64_t nt = (Lfull + V - 1) / V;
     const int64_t items = ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt * per_item_units;
     const int64_t slots = (int64_t)cus * c.wgs_per_cu;
     const double est = (double)((items + slots - 1) / slots) * c.t_item;
     if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; }
   }
-  if (best_T == 0) return FC_OK;                    // kernel too long for these tiles: general planner decides
-  if (want > 0 && best_nb == 0) return FC_OK;
+  if (best_T == 0) return FC_OK;                    // general planner (cost model) decides
   *tile_out = best_T;
   p->pers_nb_choice = best_nb;
   return FC_OK;

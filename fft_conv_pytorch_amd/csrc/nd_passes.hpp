@@ -384,14 +384,21 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
 
-  // id = ((((b*ntiles + tile)*n_ochunks + oc)*G + g)*ncol + col): neighbouring workgroups share (g, oc)
-  // weights of neighbouring columns
+  // XCD-aware unit map.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2), and
+  // a column's kernel spectrum (Cog x Cig x T complex, e.g. 256 KB) is read by every batch item of
+  // that column: so the column is tied to id % 8 and the batch index runs fastest behind it --
+  // all B workgroups of a column hit the same L2 back to back and the spectrum leaves the
+  // Infinity Cache once per XCD instead of once per workgroup.
+  //   id = ((((tile*n_ochunks + oc)*G + g)*ncb + colblk)*B + b)*8 + xcd ,  col = colblk*8 + xcd
   int id = blockIdx.x;
-  const int col = id % a.ncol; id /= a.ncol;
+  const int xcd = id & 7; id >>= 3;
+  const int b = id % a.B; id /= a.B;
+  const int ncb = (a.ncol + 7) >> 3;
+  const int col = (id % ncb) * 8 + xcd; id /= ncb;
   const int g = id % a.G; id /= a.G;
-  const int oc = id % a.n_ochunks; id /= a.n_ochunks;
-  const int tile = id % a.ntiles;
-  const int b = id / a.ntiles;
+  const int oc = id % a.n_ochunks;
+  const int tile = id / a.n_ochunks;
+  if (col >= a.ncol) return;                 // padding of the last column block (uniform per workgroup)
 
   f2* zin = lds;
   f2* vout = a.accumulate ? lds + CIB * LSEQP : lds;
@@ -414,24 +421,56 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
       fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA, twB);
     }
     __syncthreads();
-    // mix: every bin is independent in complex mode
-    for (int f = tid; f < T; f += NT) {
+    // mix: every bin is independent in complex mode.  step = (bin of this thread, output channel o);
+    // two register sets alternate so the CIB/2 spectrum loads of the next step are in flight while
+    // this one is contracted (same scheme as the 1-D kernel).
+    {
+      constexpr int BPT = (T + NT - 1) / NT;              // bins per thread
+      constexpr int NH = CIB / 2;
+      const int nsteps = BPT * a.cob;
+      const size_t orow = (size_t)(a.Cig_pad / 2) * wcol;  // float4 between output channels
+      const f4* wbase = wgrp + ((size_t)(oc * a.cob) * (a.Cig_pad / 2) + ic * NH) * wcol;
+      f4 wA[NH], wB[NH];
       f2 x[CIB];
+      auto issue = [&](int m, int o, f4 (&dst)[NH]) {
+        const int f = min(tid + m * NT, T - 1);
+        const f4* w = wbase + (size_t)o * orow + f;
 #pragma unroll
-      for (int i = 0; i < CIB; ++i) x[i] = zin[i * LSEQP + G::nat(f)];
-#pragma unroll 1
-      for (int o = 0; o < a.cob; ++o) {
-        const f4* w = wgrp + ((size_t)(oc * a.cob + o) * (a.Cig_pad / 2) + ic * (CIB / 2)) * wcol + f;
+        for (int p = 0; p < NH; ++p) dst[p] = w[(size_t)p * wcol];
+      };
+      auto step = [&](int m, int o, const f4 (&wc)[NH]) {
+        const int f = tid + m * NT;
+        const bool live = f < T;
+        const int fc = live ? f : 0;
+        if (o == 0) {
+#pragma unroll
+          for (int i = 0; i < CIB; ++i) x[i] = zin[i * LSEQP + G::nat(fc)];
+        }
         f2 y = mk2(0.f, 0.f);
 #pragma unroll
-        for (int p = 0; p < CIB / 2; ++p) {
-          const f4 h = w[(size_t)p * wcol];
-          cmac(y, x[2 * p], h.xy);
-          cmac(y, x[2 * p + 1], h.zw);
+        for (int p = 0; p < NH; ++p) {
+          cmac(y, x[2 * p], wc[p].xy);
+          cmac(y, x[2 * p + 1], wc[p].zw);
         }
-        f2* pv = vout + o * LSEQP + G::nat(f);
-        if (ic != 0) y += *pv;
-        *pv = y;
+        if (live) {
+          f2* pv = vout + o * LSEQP + G::nat(fc);
+          if (ic != 0) y += *pv;
+          *pv = y;
+        }
+      };
+      int m = 0, o = 0;
+      issue(0, 0, wA);
+#pragma unroll 1
+      for (int s2 = 0; s2 < nsteps; s2 += 2) {
+        int o1 = o + 1, m1 = m;
+        if (o1 == a.cob) { o1 = 0; ++m1; }
+        int o2 = o1 + 1, m2 = m1;
+        if (o2 == a.cob) { o2 = 0; ++m2; }
+        if (s2 + 1 < nsteps) issue(m1, o1, wB);
+        step(m, o, wA);
+        if (s2 + 2 < nsteps) issue(m2, o2, wA);
+        if (s2 + 1 < nsteps) step(m1, o1, wB);
+        m = m2; o = o2;
       }
     }
     __syncthreads();

@@ -120,7 +120,7 @@ hipError_t launch_fusedc(const FusedCArgs& a, hipStream_t st) {
     static bool done = false;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;
-    const long long grid = (long long)a.B * a.ntiles * a.n_ochunks * a.G * a.ncol;
+    const long long grid = (long long)a.B * a.ntiles * a.n_ochunks * a.G * ((a.ncol + 7) / 8) * 8;
     if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
     return hipGetLastError();

@@ -56,6 +56,19 @@ def algorithmic_bytes(batch, cin, cout, groups, spatial, kernel, out_spatial):
     return 4 * (n_in + n_w + cout + n_out), n_out
 
 
+def pmc_traffic(config_name, tile):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (collected
+    separately: counters cannot be read from inside the timed run).  None when no matching profile."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_cfgA_pmc.json")) as fh:
+            prof = json.load(fh)
+        if prof.get("workload") == config_name and f"tile {tile}" in prof.get("kernel", ""):
+            return prof["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """The reference's CPU op sequence (oracle/fft_conv_oracle.py, torch CPU backend) timed on this
     host's cores on a bounded sample: whole batches of the same workload until the budget is spent."""
@@ -214,7 +227,7 @@ def main():
                        "tile": plan.tile, "buffer_sets": nbuf, "hip_graph": graph is not None,
                        "kernel_spectrum": "cached per weight version (FFTConv module)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, plan.tile),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_us": kernel_us},
         }
         if not args.no_cpu_baseline and world == 1:

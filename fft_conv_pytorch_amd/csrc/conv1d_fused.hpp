@@ -160,14 +160,14 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       passA_fft_twiddle_store<G, -1>(v, zin + sq * G::LSEQ, tseq, twA);
     }
     stamp(a.stamps, 2);
-    __syncthreads();
+    seq_sync<G>();
     stamp(a.stamps, 3);
     // ------------------------------------------------ forward pass B (LDS -> regs -> LDS natural)
     {
       // every row is read before anyone writes: the two layouts alias
       f2 v[P];
       if (seq0 < NPI) passB_load<G>(v, zin + seq0 * G::LSEQ, tseq);
-      __syncthreads();
+      seq_sync<G>();
       if (seq0 < NPI) {
         const int j = passB_compute<G, -1>(v, tseq, twB);
         const int k1 = tseq >> G::LGS;
@@ -286,13 +286,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
 #pragma unroll
       for (int i1 = 0; i1 < P; ++i1) v[i1] = src[G::nat(G::N2 * i1 + tseq)];
     }
-    __syncthreads();
+    seq_sync<G>();
     if (act) {
       passA_fft_twiddle_store<G, +1>(v, vout + seq0 * G::LSEQ, tseq, twA);
     }
   }
   stamp(a.stamps, 8);
-  __syncthreads();
+  seq_sync<G>();
   stamp(a.stamps, 9);
   // -------------------------------------------------- inverse pass B' (LDS -> regs -> HBM)
   if (seq0 < npo) {

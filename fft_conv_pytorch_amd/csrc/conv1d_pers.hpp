@@ -110,13 +110,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       }
     }
     stamp_item(a.stamps, it, 2);
-    __syncthreads();
+    seq_sync<G>();
     stamp_item(a.stamps, it, 3);
     // ------------------------------------------------ forward pass B
     {
       f2 v[P];
       if (act_in) passB_load<G>(v, zseq, tseq);
-      __syncthreads();
+      seq_sync<G>();
       if (act_in) {
         const int j = passB_compute<G, -1>(v, tseq, twB);
         const int k1 = tseq >> G::LGS;
@@ -248,14 +248,14 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
         for (int i1 = 0; i1 < P; ++i1) v[i1] = zseq[G::nat(G::N2 * i1 + tseq)];
       }
-      __syncthreads();
+      seq_sync<G>();
       if (act_out) {
         fft_regs<P, +1>(v);
         passA_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
       }
     }
     stamp_item(a.stamps, it, 8);
-    __syncthreads();
+    seq_sync<G>();
     stamp_item(a.stamps, it, 9);
     // ------------------------------------------------ inverse pass B' + store
     if (act_out) {

@@ -192,6 +192,20 @@ struct Geo {
   __device__ static constexpr int nat(int f) { return f + NATPAD * (f / (P * P)); }
 };
 
+// Synchronisation between the two passes of ONE sequence.  A sequence is owned by TS = P*S
+// consecutive threads; for TS <= 64 they all sit in one wavefront, whose LDS instructions execute
+// in program order, so a compiler-level fence is enough and the workgroup barrier (and the skew
+// it exposes between waves) disappears.  Only the 4096-point tile (TS = 128) needs s_barrier.
+template <class G>
+__device__ __forceinline__ void seq_sync() {
+  if constexpr (G::TS > 64) {
+    __syncthreads();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // Multiply by the pass-A twiddles and write A[k1][n2] (padded rows).
 //   twA[k1*N2 + n2] = exp(-2*pi*i*n2*k1/T)  (forward sign; conjugated for DIR=+1)
 template <class G>

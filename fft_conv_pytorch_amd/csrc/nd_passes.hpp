@@ -47,16 +47,16 @@ __device__ __forceinline__ int tap_src(int p, int dil, int k) {
 
 // ------------------------------------------------------------------------------------------
 // forward passes on one sequence whose P inputs per thread are already in registers;
-// leaves the natural-order spectrum in lseq.  Contains two barriers: every thread of the
-// workgroup must call it (idle threads pass act = false).
+// leaves the natural-order spectrum in lseq.  Contains two sequence syncs (workgroup barriers only
+// for the 4096-point tile): every thread of the workgroup must call it (idle threads pass act = false).
 template <class G>
 __device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA, BufRsrc twB) {
   if (act) {
     passA_fft_twiddle_store<G, -1>(v, lseq, tseq, twA);
   }
-  __syncthreads();
+  seq_sync<G>();
   if (act) passB_load<G>(v, lseq, tseq);
-  __syncthreads();
+  seq_sync<G>();
   if (act) {
     const int j = passB_compute<G, -1>(v, tseq, twB);
     const int k1 = tseq >> G::LGS;
@@ -74,11 +74,11 @@ __device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bo
 #pragma unroll
     for (int i1 = 0; i1 < G::P; ++i1) v[i1] = lseq[G::nat(G::N2 * i1 + tseq)];
   }
-  __syncthreads();
+  seq_sync<G>();
   if (act) {
     passA_fft_twiddle_store<G, +1>(v, lseq, tseq, twA);
   }
-  __syncthreads();
+  seq_sync<G>();
   int j = 0;
   if (act) {
     passB_load<G>(v, lseq, tseq);

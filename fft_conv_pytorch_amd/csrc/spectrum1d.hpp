@@ -58,18 +58,18 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
     }
     passA_fft_twiddle_store<G, -1>(v, z, tseq, twA);
   }
-  __syncthreads();
+  seq_sync<G>();
   {
     f2 v[P];
     passB_load<G>(v, z, tseq);
-    __syncthreads();
+    seq_sync<G>();
     const int j = passB_compute<G, -1>(v, tseq, twB);
     const int k1 = tseq >> G::LGS;
     f2* dst = z + G::nat(k1 + P * P * j);
 #pragma unroll
     for (int k = 0; k < P; ++k) dst[P * k] = v[k];
   }
-  __syncthreads();
+  seq_sync<G>();
   if (!act) return;
   const float sc = 0.5f / (float)T;
   f4* out = a.wspec + (size_t)seq * (T / 2);

@@ -111,11 +111,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.tile:
         os.environ["FFTCONV_TILE"] = str(args.tile)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (single-GPU box): several ranks on one device, gloo instead of RCCL
+    dev_index = int(os.environ.get("FFTCONV_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("FFTCONV_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import fft_conv_pytorch_amd as fca
     from fft_conv_pytorch_amd import _native

@@ -595,6 +595,10 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1; r.transposed = 0; r.Cig = p.Cig; r.Cog = p.Cog;
   r.NA = B * Ci; r.NC = nd == 3 ? p.Sp[0] : 1; r.NY = p.Sp[nd - 2]; r.NYa = r.NY;
   r.SZ = nd == 3 ? (int)p.d.spatial[0] : 1; r.SY = (int)p.d.spatial[nd - 2]; r.SX = (int)p.d.spatial[nd - 1]; r.Fx = p.Fx;
+  {
+    const unsigned long long bytes = 4ull * (unsigned long long)B * Ci * r.SZ * r.SY * r.SX;
+    r.src_bytes = bytes < 0xFFFFFFFFull ? (unsigned)bytes : 0u;
+  }
   FC_HIP(p.tx->rows_r2c(r, st));
 
   fc::FusedCArgs f{};

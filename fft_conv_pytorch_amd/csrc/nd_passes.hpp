@@ -108,6 +108,7 @@ struct RowsR2CArgs {
   int NA, NC, NY, NYa;   // images, planes per image (padded), rows per plane (padded), row stride of dst
   int SZ, SY, SX;        // source extents (signal: unpadded sizes; kernel: taps)
   int Fx;                // T/2 + 1
+  unsigned src_bytes;    // size of the source tensor when it fits 32-bit buffer offsets, else 0
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -153,18 +154,33 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
       }
       rows[h] = a.src + ((simg * a.SZ + (ok[h] ? zs : 0)) * a.SY + (ok[h] ? ys : 0)) * a.SX;
     }
-    f2* col = lds + sq * LSEQP + tseq;
-#pragma unroll 1
-    for (int n1 = 0; n1 < P; ++n1) {
-      const int xp = G::N2 * n1 + tseq;
-      int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
-      if (a.from_kernel && a.transposed && xs >= 0) xs = a.SX - 1 - xs;
-      const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
-      const float v1 = (ok[1] && xs >= 0) ? rows[1][xs] : 0.f;
-      col[n1 * G::RS] = mk2(v0, v1);
-    }
+    if (!a.from_kernel && a.mx.up == 1 && a.mx.mode == PAD_CONSTANT && a.src_bytes != 0) {
+      // fast path (zero padding): unrolled buffer loads over the whole source tensor; a sample outside
+      // its row gets an out-of-range offset and reads as zero -- no masks live across the loads
+      const BufRsrc sg = make_rsrc(a.src, a.src_bytes);
+      const unsigned ro0 = ok[0] ? (unsigned)((rows[0] - a.src) * 4) : 0xFFFFFFFFu;
+      const unsigned ro1 = ok[1] ? (unsigned)((rows[1] - a.src) * 4) : 0xFFFFFFFFu;
 #pragma unroll
-    for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int xs = G::N2 * n1 + tseq - a.mx.pad;
+        const bool in = (unsigned)xs < (unsigned)a.SX;
+        v[n1].x = buf_load_f32(sg, (in && ok[0]) ? ro0 + (unsigned)xs * 4u : 0xFFFFFFFFu, 0);
+        v[n1].y = buf_load_f32(sg, (in && ok[1]) ? ro1 + (unsigned)xs * 4u : 0xFFFFFFFFu, 0);
+      }
+    } else {
+      f2* col = lds + sq * LSEQP + tseq;
+#pragma unroll 1
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int xp = G::N2 * n1 + tseq;
+        int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
+        if (a.from_kernel && a.transposed && xs >= 0) xs = a.SX - 1 - xs;
+        const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
+        const float v1 = (ok[1] && xs >= 0) ? rows[1][xs] : 0.f;
+        col[n1 * G::RS] = mk2(v0, v1);
+      }
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
+    }
   }
   fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
   __syncthreads();
@@ -348,6 +364,18 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   float* o1 = o0 + a.Xo;
   const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;
   const int nbase = (tseq >> G::LGS) + P * P * j;
+  if (a.stride == 1) {
+    if (has1) {
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        if (nbase + P * k < a.NV) { o0[nbase + P * k] = v[k].x + b; o1[nbase + P * k] = v[k].y + b; }
+    } else if (has0) {
+#pragma unroll
+      for (int k = 0; k < P; ++k)
+        if (nbase + P * k < a.NV) o0[nbase + P * k] = v[k].x + b;
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < P; ++k) {
     const int n = nbase + P * k;

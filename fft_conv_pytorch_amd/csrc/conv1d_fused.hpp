@@ -78,6 +78,17 @@ __device__ __forceinline__ float load_padded(const float* __restrict__ row, int 
   return ok ? v : 0.0f;
 }
 
+// Byte offset of padded position pos inside a row starting at row_off, or an out-of-range offset
+// (buffer loads then return zero) -- the mask is consumed before the load, nothing stays live.
+__device__ __forceinline__ unsigned padded_offset(unsigned row_off, int pos, int L, int pad, const PadMap& m, bool chan_ok) {
+  const bool inside = (unsigned)pos < (unsigned)L;
+  const int qm = (pos < 0) ? m.lo_a * pos + m.lo_b : m.hi_a * pos + m.hi_b;
+  int q = inside ? pos : qm;
+  q = min(max(q, 0), L - 1);
+  const bool ok = chan_ok && (inside || (m.live && pos >= -pad && pos < L + pad));
+  return ok ? row_off + (unsigned)q * 4u : 0xFFFFFFFFu;
+}
+
 // Profiling hook: lane 0 of each workgroup records the 100 MHz wall clock at phase boundaries.
 __device__ __forceinline__ void stamp(unsigned long long* buf, int slot) {
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();
@@ -141,9 +152,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
         }
       } else {
-        // border tile / odd channel count: a rolled loop stages this thread's own
-        // column in LDS (no long-lived masks, no register-array indexing), then the
-        // column is read back -- same thread, same addresses, so no barrier.
+        // border tile / odd channel count / zero-spread source of a transposed plan: a rolled loop
+        // stages this thread's own column in LDS (no long-lived masks, no register-array indexing),
+        // then the column is read back -- same thread, same addresses, so no barrier.  (An unrolled
+        // masked-offset variant is used by the batch-sharing kernel; here it made hipcc spill.)
         f2* col = zin + sq * G::LSEQ + tseq;
 #pragma unroll 1
         for (int n1 = 0; n1 < P; ++n1) {

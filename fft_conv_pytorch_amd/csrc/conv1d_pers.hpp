@@ -91,6 +91,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
           v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
         }
+      } else if (a.up == 1) {
+        const unsigned ro0 = ((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
+        const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int pos = tile_pos + G::N2 * n1 + tseq;
+          v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
+          v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
+        }
       } else {
         const float* r0 = xbase + ((size_t)(act_in ? nb : 0) * a.Cin + (has0 ? ci0 : 0)) * a.L;
         const float* r1 = has1 ? r0 + a.L : r0;

@@ -264,7 +264,18 @@ static int plan_1d_persistent(fc_plan* p) {
   std::vector<fc::WorkItem> items;
   const int nfull = (int)(B / nb), rem = (int)(B % nb);
   const int64_t slots = (int64_t)cus * wgs_per_cu;
-  for (int tile = 0; tile < p->ntiles; ++tile)
+  // border tiles (staged, slower loads) are issued first so they never form the tail of the launch
+  std::vector<int> tile_order;
+  {
+    const int T = t->T, V = p->V;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int tile = 0; tile < p->ntiles; ++tile) {
+        const int64_t pos = (int64_t)tile * V - p->padl[0];
+        const bool interior = p->up[0] == 1 && pos >= 0 && pos + T <= d.spatial[0];
+        if ((pass == 0) == !interior) tile_order.push_back(tile);
+      }
+  }
+  for (int tile : tile_order)
     for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
       for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
   if (nb >= 2 && (int64_t)items.size() > slots) {

@@ -48,3 +48,11 @@ print(f"workgroup lifetime median {np.median(life):.2f} us; start times: p50 {np
       f"p90 {np.percentile(st[:, 0] - t0, 90):.2f} max {(st[:, 0] - t0).max():.2f} us")
 hist, edges = np.histogram(st[:, 0] - t0, bins=10)
 print("start-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))
+# split by residency round (start time gap) to see whether later rounds run slower
+order = np.argsort(st[:, 0])
+half = st[:, 0] - t0 > 0.5 * np.median(life)
+for name, sel in (("first round", ~half), ("later rounds", half)):
+    if sel.any():
+        print(f"{name}: n={int(sel.sum())} lifetime p10/p50/p90/max = "
+              f"{np.percentile(life[sel], 10):.1f}/{np.median(life[sel]):.1f}/{np.percentile(life[sel], 90):.1f}/{life[sel].max():.1f} us, "
+              f"end p50/max = {np.median(st[sel, 11] - t0):.1f}/{(st[sel, 11] - t0).max():.1f} us")

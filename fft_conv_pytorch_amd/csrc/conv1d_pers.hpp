@@ -1,8 +1,11 @@
 // conv1d_pers.hpp -- persistent fused 1-D FFT convolution, NB batch items per workgroup.
 //
 // Same arithmetic as conv1d_fused.hpp (which stays the general fallback), organised for throughput:
-//   * a workgroup is resident for the whole launch and walks a host-built work list; a work item is
-//     (tile, group, out-chunk, first batch item, number of batch items <= NB);
+//   * work items come from a host-built list; an item is (tile, group, out-chunk, first batch item,
+//     number of batch items <= NB).  A workgroup runs up to TWO items back to back (written out twice,
+//     not as a loop: hipcc spills the FFT registers around every barrier when the body sits in a loop)
+//     and requests the second item's input samples while the first is in its inverse passes, so the
+//     HBM reads of one item hide behind the arithmetic of the other;
 //   * the NB batch items of an item share every kernel-spectrum load of the mix step, which is what
 //     bounds the one-item-per-workgroup kernel (L2 -> L1 traffic of the spectrum);
 //   * the pass-A twiddle table lives in LDS for the lifetime of the workgroup;
@@ -38,6 +41,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   constexpr int NSEQ = NB * NPI;
   static_assert(NT == NSEQ * G::TS, "one thread slot per point group of every sequence");
   static_assert((T / 2) % NT == 0, "bin pairs divide evenly over the threads");
+  static_assert(NPI % 2 == 0, "the spectrum pipeline alternates two register sets");
+  static_assert(NB * CIB * 2 <= 64, "the self-paired bins are handled by one wave");
   constexpr int BP = (T / 2) / NT;          // bin pairs per thread
   constexpr int TWN = P * G::N2;            // pass-A twiddle table entries
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
@@ -47,7 +52,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const int sq = tid / G::TS;               // sequence slot: batch slot nb, channel pair p
   const int tseq = tid % G::TS;
   const int nb = sq / NPI, pr = sq % NPI;
-  constexpr int npo = NPI;                  // full output chunks only
   f2* twl = lds;
   f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ]
   f2* zseq = zbuf + sq * G::LSEQ;
@@ -58,81 +62,64 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   __syncthreads();
 
-  // one work item per workgroup: a resident loop over items made hipcc hoist per-item invariants
-  // across the whole kernel and spill the FFT registers around every barrier
-  {
-    const int it = blockIdx.x;
-    const WorkItem wi = pa.items[it];
-    const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
-    const int tile = wi.tile;
-    const int tile_pos = tile * a.V - a.pad;
+  // ---- input samples of one item -> registers (unrolled buffer loads; border tiles get per-sample
+  // padded / out-of-range offsets).  Only requests: nothing waits here.
+  auto fetch = [&](const WorkItem& wi, f2 (&v)[P]) {
+    const int g = wi.goc / a.n_ochunks;
+    const int tile_pos = wi.tile * a.V - a.pad;
     const bool interior = (tile_pos >= 0) && (tile_pos + T <= a.L);
     const bool act_in = nb < wi.nbc;
-    // descriptor over the NB batch items' slab of this group: uniform base, lane part in the offset
     const float* xbase = a.x + ((size_t)wi.b0 * a.Cin + (size_t)g * a.Cig) * a.L;
     const BufRsrc xg = make_rsrc(xbase, (unsigned)(((size_t)(wi.nbc - 1) * a.Cin + a.Cig) * a.L * 4));
-    const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
+    const int ci0 = 2 * pr;
+    const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
+    const unsigned ro0 = ((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
+    const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
+    if (interior && has1) {
+      const unsigned v0 = ro0 + (unsigned)(tile_pos + tseq) * 4u, v1 = ro1 + (unsigned)(tile_pos + tseq) * 4u;
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+        v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int pos = tile_pos + G::N2 * n1 + tseq;
+        v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
+        v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
+      }
+    }
+  };
 
+  // ---- one item: forward FFT, mix, [request the next item's samples], inverse FFT, store
+  auto run = [&](const WorkItem& wi, int it, f2 (&v)[P], bool more, const WorkItem& wnext, f2 (&vnext)[P]) {
+    const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
+    const bool act_in = nb < wi.nbc;
+    const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
     stamp_item(a.stamps, it, 0);
     // bias of this lane's two output channels, requested now and used in the last pass
     const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
     const float bias0 = a.bias ? a.bias[cg0] : 0.f;
     const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
     // ------------------------------------------------ forward pass A
-    {
-      f2 v[P];
-      const int ci0 = 2 * pr;
-      const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
-      if (interior && has1) {
-        const unsigned v0 = (((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L + (unsigned)(tile_pos + tseq)) * 4u;
-        const unsigned v1 = v0 + (unsigned)a.L * 4u;
-#pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
-          v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
-          v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
-        }
-      } else if (a.up == 1) {
-        const unsigned ro0 = ((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
-        const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
-#pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
-          const int pos = tile_pos + G::N2 * n1 + tseq;
-          v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
-          v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
-        }
-      } else {
-        const float* r0 = xbase + ((size_t)(act_in ? nb : 0) * a.Cin + (has0 ? ci0 : 0)) * a.L;
-        const float* r1 = has1 ? r0 + a.L : r0;
-        f2* col = zseq + tseq;
-#pragma unroll 1
-        for (int n1 = 0; n1 < P; ++n1) {
-          const int pos = tile_pos + G::N2 * n1 + tseq;
-          col[n1 * G::RS] = mk2(load_padded(r0, pos, a.L, a.pad, pm, has0), load_padded(r1, pos, a.L, a.pad, pm, has1));
-        }
-#pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
-      }
-      if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
-      if (act_in) {
-        fft_regs<P, -1>(v);
-        passA_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
-      }
+    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
+    if (act_in) {
+      fft_regs<P, -1>(v);
+      passA_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
     }
     stamp_item(a.stamps, it, 2);
     seq_sync<G>();
     stamp_item(a.stamps, it, 3);
     // ------------------------------------------------ forward pass B
-    {
-      f2 v[P];
-      if (act_in) passB_load<G>(v, zseq, tseq);
-      seq_sync<G>();
-      if (act_in) {
-        const int j = passB_compute<G, -1>(v, tseq, twB);
-        const int k1 = tseq >> G::LGS;
-        f2* dst = zseq + G::nat(k1 + P * P * j);
+    if (act_in) passB_load<G>(v, zseq, tseq);
+    seq_sync<G>();
+    if (act_in) {
+      const int j = passB_compute<G, -1>(v, tseq, twB);
+      const int k1 = tseq >> G::LGS;
+      f2* dst = zseq + G::nat(k1 + P * P * j);
 #pragma unroll
-        for (int k = 0; k < P; ++k) dst[P * k] = v[k];
-      }
+      for (int k = 0; k < P; ++k) dst[P * k] = v[k];
     }
     stamp_item(a.stamps, it, 4);
     __syncthreads();
@@ -144,7 +131,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
       // lane (batch b, output o, bin) of wave 0 owns one real output.  Its loads are issued here and
       // consumed after the main loop, so their latency is hidden (a one-lane serial loop cost ~8 us).
-      static_assert(NB * CIB * 2 <= 64, "the self-paired bins are handled by one wave");
       const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
       const bool sb_act = tid < NB * CIB * 2 && sb_b < wi.nbc;
       f4 sbw[NPI];
@@ -156,16 +142,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           sbz[p] = zbuf[(sb_b * NPI + p) * G::LSEQ + G::nat(sb_f)];
         }
       }
-      // spectrum pipeline: step = (bin pair m, output pair q); the 2*NPI float4 of the next step are
-      // requested before the current step is contracted (two named register sets, static indices)
+      // spectrum pipeline: step = (bin pair m, output pair q); two named register sets (static
+      // indices): the 2*NPI float4 of the next step are in flight while this one is contracted
       auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
         const unsigned vo = (unsigned)(tid + m * NT) * 16u;
         const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-        if (pa.debug_mode == 1) {
-#pragma unroll
-          for (int p = 0; p < 2 * NPI; ++p) { dst[p].x = 1.f; dst[p].y = 0.5f; dst[p].z = 0.25f; dst[p].w = 2.f; }
-          return;
-        }
 #pragma unroll
         for (int p = 0; p < NPI; ++p) {
           dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
@@ -174,45 +155,26 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       };
       f2 xe[NB][NPI], xo[NB][NPI];       // 2*X of the even / odd channel of every pair
       auto contract = [&](int f, int fm, int q, const f4 (&wc)[2 * NPI]) {
-        if (pa.debug_mode == 2) {
 #pragma unroll
-          for (int p = 0; p < 2 * NPI; ++p) asm volatile("" :: "v"(wc[p].x), "v"(wc[p].y), "v"(wc[p].z), "v"(wc[p].w));
-          return;
-        }
-        if (q < npo) {
+        for (int b = 0; b < NB; ++b) {
+          f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
-#pragma unroll
-            for (int p = 0; p < NPI; ++p) {
-              const f4 ha = wc[2 * p], hb = wc[2 * p + 1];
-              cmac(ya, xe[b][p], ha.xy); cmac(ya, xo[b][p], ha.zw);
-              cmac(yb, xe[b][p], hb.xy); cmac(yb, xo[b][p], hb.zw);
-            }
-            if (f != 0 && b < wi.nbc) {
-              f2* zb = zbuf + (b * NPI + q) * G::LSEQ;
-              zb[G::nat(f)] = add_pi(ya, yb);
-              zb[G::nat(fm)] = conj_add_iconj(ya, yb);
-            }
+          for (int p = 0; p < NPI; ++p) {
+            const f4 ha = wc[2 * p], hb = wc[2 * p + 1];
+            cmac(ya, xe[b][p], ha.xy); cmac(ya, xo[b][p], ha.zw);
+            cmac(yb, xe[b][p], hb.xy); cmac(yb, xo[b][p], hb.zw);
+          }
+          if (f != 0 && b < wi.nbc) {
+            f2* zb = zbuf + (b * NPI + q) * G::LSEQ;
+            zb[G::nat(f)] = add_pi(ya, yb);
+            zb[G::nat(fm)] = conj_add_iconj(ya, yb);
           }
         }
       };
-      // Two named register sets (static indices), rolled over the bin pairs.  The walk through
-      // (bin pair, output pair) starts at a different point in every workgroup: all workgroups
-      // stream the same spectrum at the same time, and walking it in lock-step piles every CU's
-      // requests onto the same L2 channels.
-      // Two named register sets (static indices), rolled over the bin pairs: the loads of the next
-      // step are in flight while the current one is contracted.  (Deeper rings were tried: with 256
-      // VGPRs hipcc spills them and the mix gets slower; the mix is bound by the ~70 GB/s per-CU
-      // L2 -> L1 rate, not by latency.)  Workgroups start their walk at different bin pairs.
-      static_assert(NPI % 2 == 0, "pipeline alternates two register sets");
       f4 wA[2 * NPI], wB[2 * NPI];
-      const int m0 = (int)(blockIdx.x % BP);
-      auto mrot = [&](int m) { const int r = m + m0; return r >= BP ? r - BP : r; };
-      issue(mrot(0), 0, wA);
+      issue(0, 0, wA);
 #pragma unroll 1
-      for (int mi = 0; mi < BP; ++mi) {
-        const int m = mrot(mi);
+      for (int m = 0; m < BP; ++m) {
         const int f = tid + m * NT;
         const int fm = (T - f) & (T - 1);
 #pragma unroll
@@ -231,7 +193,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           issue(m, q + 1, wB);
           contract(f, fm, q, wA);
           if (q + 2 < NPI) issue(m, q + 2, wA);
-          else if (mi + 1 < BP) issue(mrot(mi + 1), 0, wA);
+          else if (m + 1 < BP) issue(m + 1, 0, wA);
           contract(f, fm, q + 1, wB);
         }
       }
@@ -249,30 +211,27 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     stamp_item(a.stamps, it, 6);
     __syncthreads();
     stamp_item(a.stamps, it, 7);
+    // the next item's samples travel from HBM while this item's inverse passes run
+    if (more) fetch(wnext, vnext);
     // ------------------------------------------------ inverse pass A'
-    const bool act_out = act_in && pr < npo;
-    {
-      f2 v[P];
-      if (act_out) {
+    if (act_in) {
 #pragma unroll
-        for (int i1 = 0; i1 < P; ++i1) v[i1] = zseq[G::nat(G::N2 * i1 + tseq)];
-      }
-      seq_sync<G>();
-      if (act_out) {
-        fft_regs<P, +1>(v);
-        passA_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
-      }
+      for (int i1 = 0; i1 < P; ++i1) v[i1] = zseq[G::nat(G::N2 * i1 + tseq)];
+    }
+    seq_sync<G>();
+    if (act_in) {
+      fft_regs<P, +1>(v);
+      passA_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
     }
     stamp_item(a.stamps, it, 8);
     seq_sync<G>();
     stamp_item(a.stamps, it, 9);
     // ------------------------------------------------ inverse pass B' + store
-    if (act_out) {
-      f2 v[P];
+    if (act_in) {
       passB_load<G>(v, zseq, tseq);
       const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;
-      const int t0 = tile * a.V;
+      const int t0 = wi.tile * a.V;
       const int limit = min(a.V, a.Lfull - t0);
       const int nbase = o1 + P * P * j;
       float* y0 = a.y + ((size_t)(wi.b0 + nb) * a.Cout + cg0) * a.Lout + t0 + nbase;
@@ -283,8 +242,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     }
     stamp_item(a.stamps, it, 10);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }
-    __syncthreads();   // the sequence buffers are reused by the next item
-  }
+    seq_sync<G>();     // this wave's sequences are free again (the mix barriers order the other waves)
+  };
+
+  const int it0 = blockIdx.x, it1 = blockIdx.x + gridDim.x;
+  const bool two = it1 < pa.n_items;
+  const WorkItem w0 = pa.items[it0];
+  const WorkItem w1 = pa.items[two ? it1 : it0];
+  f2 va[P], vb[P];
+  fetch(w0, va);
+  run(w0, it0, va, two, w1, vb);
+  if (two) run(w1, it1, vb, false, w1, va);
 }
 
 }  // namespace fc

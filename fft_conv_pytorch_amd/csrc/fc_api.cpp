@@ -217,7 +217,7 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
   const Cand cands[] = {{256, 0, 8, 10.9}, {512, 0, 6, 10.4}, {1024, 0, 4, 24.0}, {2048, 0, 2, 26.4},
-                        {2048, 2, 1, 20.1}, {1024, 2, 2, 14.7}, {1024, 4, 1, 16.8}};
+                        {2048, 2, 1, 19.5}, {1024, 2, 2, 16.0}, {1024, 4, 1, 15.0}};
   double best = 0;
   int best_T = 0, best_nb = 0;
   for (const Cand& c : cands) {
@@ -297,7 +297,8 @@ static int plan_1d_persistent(fc_plan* p) {
       for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) items.push_back({nfull * nb, rem, tile, goc});
   if (items.size() > 0x7fffffffu) return FC_OK;
   p->pers_items = (int)items.size();
-  p->pers_grid = p->pers_items;      // one item per workgroup
+  // up to two items per workgroup (the second one's input is prefetched): item i and i + grid
+  p->pers_grid = (int)std::max<int64_t>((p->pers_items + 1) / 2, std::min<int64_t>(p->pers_items, slots));
   FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
   FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;
@@ -584,7 +585,6 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     if (p.pers_nb) {
       fc::Conv1dPersArgs pa;
       pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;
-      pa.debug_mode = getenv("FFTCONV_DEBUG_MODE") ? atoi(getenv("FFTCONV_DEBUG_MODE")) : 0;
       FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
       return FC_OK;
     }

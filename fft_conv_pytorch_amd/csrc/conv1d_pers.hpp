@@ -56,11 +56,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ]
   f2* zseq = zbuf + sq * G::LSEQ;
 
-  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
-  __syncthreads();
 
   // ---- input samples of one item -> registers (unrolled buffer loads; border tiles get per-sample
   // padded / out-of-range offsets).  Only requests: nothing waits here.
@@ -250,7 +248,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const WorkItem w0 = pa.items[it0];
   const WorkItem w1 = pa.items[two ? it1 : it0];
   f2 va[P], vb[P];
-  fetch(w0, va);
+  fetch(w0, va);                             // first item's samples and the twiddle table travel together
+  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  __syncthreads();
   run(w0, it0, va, two, w1, vb);
   if (two) run(w1, it1, vb, false, w1, va);
 }

@@ -26,7 +26,6 @@ struct Conv1dPersArgs {
   Conv1dArgs c;
   const WorkItem* items;
   int n_items;
-  int debug_mode;   // experiments: 1 = mix without spectrum loads, 2 = mix without contraction, 3 = no LDS traffic in mix
 };
 
 __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, int slot) {
@@ -51,7 +50,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const int tid = threadIdx.x;
   const int sq = tid / G::TS;               // sequence slot: batch slot nb, channel pair p
   const int tseq = tid % G::TS;
-  const int nb = sq / NPI, pr = sq % NPI;
+  static_assert(G::TS <= 64 && (NPI * G::TS) % 64 == 0, "a batch slot is a whole number of wavefronts");
+  const int nb = __builtin_amdgcn_readfirstlane(tid / (NPI * G::TS)), pr = sq % NPI;   // batch slot: wave-uniform
   f2* twl = lds;
   f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ]
   f2* zseq = zbuf + sq * G::LSEQ;
@@ -102,17 +102,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
     // ------------------------------------------------ forward pass A
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
+    // (act_in is wave-uniform and the two passes of a sequence only need wave-level ordering)
     if (act_in) {
-      fft_regs<P, -1>(v);
-      passA_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
-    }
-    stamp_item(a.stamps, it, 2);
-    seq_sync<G>();
-    stamp_item(a.stamps, it, 3);
-    // ------------------------------------------------ forward pass B
-    if (act_in) passB_load<G>(v, zseq, tseq);
-    seq_sync<G>();
-    if (act_in) {
+      passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
+      stamp_item(a.stamps, it, 2);
+      seq_sync<G>();
+      stamp_item(a.stamps, it, 3);
+      // ---------------------------------------------- forward pass B
+      passB_load<G>(v, zseq, tseq);
+      seq_sync<G>();
       const int j = passB_compute<G, -1>(v, tseq, twB);
       const int k1 = tseq >> G::LGS;
       f2* dst = zseq + G::nat(k1 + P * P * j);
@@ -175,16 +173,28 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       for (int m = 0; m < BP; ++m) {
         const int f = tid + m * NT;
         const int fm = (T - f) & (T - 1);
+        {
+          // all 2*NB*NPI bin reads are requested first (plain ds_read_b64), then combined
+          const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
+          static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const unsigned bf = af + b * NPI * G::LSEQ * 8, bg = ag + b * NPI * G::LSEQ * 8;
+            static_for<0, NPI>([&](auto pc) {
+              constexpr int p = decltype(pc)::value;
+              xe[b][p] = lds_rd<p * G::LSEQ * 8>(bf);
+              xo[b][p] = lds_rd<p * G::LSEQ * 8>(bg);
+            });
+          });
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const f2* zb = zbuf + b * NPI * G::LSEQ;
+          for (int b = 0; b < NB; ++b) { lds_arrive(xe[b]); lds_arrive(xo[b]); }
 #pragma unroll
-          for (int p = 0; p < NPI; ++p) {
-            const f2 zf = zb[p * G::LSEQ + G::nat(f)];
-            const f2 zg = zb[p * G::LSEQ + G::nat(fm)];
-            xe[b][p] = add_conj(zf, zg);
-            xo[b][p] = sub_conj_divi(zf, zg);
-          }
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) {
+              const f2 zf = xe[b][p], zg = xo[b][p];
+              xe[b][p] = add_conj(zf, zg);
+              xo[b][p] = sub_conj_divi(zf, zg);
+            }
         }
 #pragma unroll
         for (int q = 0; q < NPI; q += 2) {
@@ -213,19 +223,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     if (more) fetch(wnext, vnext);
     // ------------------------------------------------ inverse pass A'
     if (act_in) {
-#pragma unroll
-      for (int i1 = 0; i1 < P; ++i1) v[i1] = zseq[G::nat(G::N2 * i1 + tseq)];
-    }
-    seq_sync<G>();
-    if (act_in) {
-      fft_regs<P, +1>(v);
-      passA_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
-    }
-    stamp_item(a.stamps, it, 8);
-    seq_sync<G>();
-    stamp_item(a.stamps, it, 9);
-    // ------------------------------------------------ inverse pass B' + store
-    if (act_in) {
+      nat_load<G>(v, zseq, tseq);
+      seq_sync<G>();
+      passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
+      stamp_item(a.stamps, it, 8);
+      seq_sync<G>();
+      stamp_item(a.stamps, it, 9);
+      // ---------------------------------------------- inverse pass B' + store
       passB_load<G>(v, zseq, tseq);
       const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;

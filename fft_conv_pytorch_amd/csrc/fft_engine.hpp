@@ -18,6 +18,7 @@
 // No vendor FFT library is used anywhere.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace fc {
 
@@ -180,6 +181,45 @@ __device__ __forceinline__ float dpp_xor2(float v) {   // quad_perm [2,3,0,1]
 __device__ __forceinline__ f2 dpp_xor1(f2 v) { return mk2(dpp_xor1(v.x), dpp_xor1(v.y)); }
 __device__ __forceinline__ f2 dpp_xor2(f2 v) { return mk2(dpp_xor2(v.x), dpp_xor2(v.y)); }
 
+// ---------------------------------------------------------------- LDS reads
+// hipcc fuses neighbouring 8-byte LDS reads into ds_read2_b64 / ds_read2st64_b64, which gfx950 serves
+// at HALF the rate of two ds_read_b64 (8 vs 2 x 2 LDS cycles per wave-instruction).  The hot loops
+// therefore issue their reads through asm (one base VGPR + immediate offsets) and wait explicitly:
+//   lds_read_strided(v, base)   requests v[i] = base[i * STRIDE]           (nothing waits)
+//   lds_arrive(v)               s_waitcnt lgkmcnt(0), then hands the values to the compiler
+// LDS returns in order, so compiler-issued LDS traffic mixed in between stays correct.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
+}
+template <int BYTES>
+__device__ __forceinline__ f2 lds_rd(unsigned addr) {
+  static_assert(BYTES >= 0 && BYTES < 65536, "ds offset field is 16 bits");
+  f2 v;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(BYTES));
+  return v;
+}
+template <int N, int STRIDE, int FIRST = 0>
+__device__ __forceinline__ void lds_read_strided(f2 (&v)[N], const f2* base) {
+  const unsigned addr = lds_off(base);
+  static_for<FIRST, N>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    v[i] = lds_rd<i * STRIDE * 8>(addr);
+  });
+}
+template <int N, int FIRST = 0>
+__device__ __forceinline__ void lds_arrive(f2 (&v)[N]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = FIRST; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
 template <int P_, int S_>
 struct Geo {
   static constexpr int P = P_, S = S_;
@@ -232,12 +272,13 @@ __device__ __forceinline__ void passA_fft_twiddle_store(f2 (&v)[G::P], f2* __res
 }
 // same with the twiddle table in LDS
 template <class G, int DIR>
-__device__ __forceinline__ void passA_twiddle_store_lds(f2 (&v)[G::P], f2* __restrict__ lseq, int n2,
-                                                        const f2* __restrict__ twl) {
-  lseq[n2] = v[0];
+__device__ __forceinline__ void passA_fft_twiddle_store_lds(f2 (&v)[G::P], f2* __restrict__ lseq, int n2,
+                                                            const f2* __restrict__ twl) {
+  fft_regs<G::P, DIR>(v);
   f2 w[G::P];
-#pragma unroll
-  for (int k1 = 1; k1 < G::P; ++k1) w[k1] = twl[k1 * G::N2 + n2];
+  lds_read_strided<G::P, G::N2, 1>(w, twl + n2);
+  lds_arrive<G::P, 1>(w);
+  lseq[n2] = v[0];
 #pragma unroll
   for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
 }
@@ -246,9 +287,18 @@ __device__ __forceinline__ void passA_twiddle_store_lds(f2 (&v)[G::P], f2* __res
 template <class G>
 __device__ __forceinline__ void passB_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {
   const int k1 = tseq >> G::LGS, r = tseq & (G::S - 1);
-  const f2* row = lseq + k1 * G::RS + r;
-#pragma unroll
-  for (int m = 0; m < G::P; ++m) v[m] = row[G::S * m];
+  lds_read_strided<G::P, G::S>(v, lseq + k1 * G::RS + r);
+  lds_arrive(v);
+}
+// Inverse pass-A load from the natural layout: v[i1] = Z[N2*i1 + tseq]
+template <class G>
+__device__ __forceinline__ void nat_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {
+  const unsigned addr = lds_off(lseq + tseq);
+  static_for<0, G::P>([&](auto ic) {
+    constexpr int i1 = decltype(ic)::value;
+    v[i1] = lds_rd<(G::N2 * i1 + G::NATPAD * (i1 / (G::P / G::S))) * 8>(addr);
+  });
+  lds_arrive(v);
 }
 
 // Pass-B compute: register FFT + lane-split finish.  Returns j such that element

@@ -26,7 +26,7 @@ step bench 400 python bench.py --steps 400 --warmup 40
 export TMPDIR=/tmp
 ROOTDIR=$(pwd)
 cd /tmp
-step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOTDIR/$OUT/prof" -- python3 "$ROOTDIR/bench.py" --steps 200 --warmup 20 --no-cpu-baseline
+step rocprof 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$ROOTDIR/bench.py" --steps 200 --warmup 20 --no-cpu-baseline
 cd "$ROOTDIR"
 find $OUT/prof -name "*stats*.csv" | head -5 | while read f; do echo "--- $f"; head -12 "$f"; done
 exit 0

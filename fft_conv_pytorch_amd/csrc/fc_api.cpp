@@ -495,7 +495,11 @@ int fc_debug_set_stamps(fc_plan* plan, void* device_buffer) {
 }
 
 long long fc_debug_grid(const fc_plan* plan) {
-  if (!plan || plan->nd != 1) return 0;
+  if (!plan) return 0;
+  if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
+    const long long ncol = plan->nd == 2 ? plan->Fx : (long long)plan->Fx * plan->tm->T;
+    return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
+  }
   if (plan->pers_nb) return plan->pers_items;
   return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->d.groups;
 }
@@ -618,6 +622,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   f.Cig_pad = p.Cig_pad; f.Cog_pad = p.nd_Cog_pad; f.cob = p.nd_cob; f.n_ochunks = p.nd_Cog_pad / p.nd_cob;
   f.Kd = (int)p.kd[0]; f.V = p.V; f.ntiles = p.ntiles; f.Lfull = p.Lfull; f.NVo = (int)p.out_sp[0];
   f.stride = p.ostride[0]; f.accumulate = p.accumulate; f.NLEN = p.Sp[0];
+  f.stamps = (unsigned long long*)p.debug_stamps;
 
   fc::RowsC2RArgs o{};
   o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;

@@ -205,6 +205,12 @@ __device__ __forceinline__ f2 lds_rd(unsigned addr) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(BYTES));
   return v;
 }
+// same for offsets beyond the 16-bit field: the excess goes into the address register
+template <int BYTES>
+__device__ __forceinline__ f2 lds_rd_far(unsigned addr) {
+  if constexpr (BYTES < 65536) return lds_rd<BYTES>(addr);
+  else return lds_rd<BYTES % 32768>(addr + (unsigned)(BYTES - BYTES % 32768));
+}
 template <int N, int STRIDE, int FIRST = 0>
 __device__ __forceinline__ void lds_read_strided(f2 (&v)[N], const f2* base) {
   const unsigned addr = lds_off(base);

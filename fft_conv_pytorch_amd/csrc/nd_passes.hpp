@@ -70,10 +70,7 @@ __device__ __forceinline__ void fwd_from_regs(f2 (&v)[G::P], f2* lseq, int tseq,
 // sample n = o1 + P*k + P*P*j (o1 = tseq >> log2 S, j returned).  Two barriers inside.
 template <class G>
 __device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bool act, BufRsrc twA, BufRsrc twB) {
-  if (act) {
-#pragma unroll
-    for (int i1 = 0; i1 < G::P; ++i1) v[i1] = lseq[G::nat(G::N2 * i1 + tseq)];
-  }
+  if (act) nat_load<G>(v, lseq, tseq);
   seq_sync<G>();
   if (act) {
     passA_fft_twiddle_store<G, +1>(v, lseq, tseq, twA);
@@ -399,37 +396,52 @@ struct FusedCArgs {
   int ncol, NLEN;        // columns per image, valid input length (zero beyond)
   int Kd, V, ntiles, Lfull, NVo, stride;
   int accumulate;
+  unsigned long long* stamps;   // profiling hook: 8 timestamps per workgroup, else null
 };
 
-template <int P, int S, int CIB, int NT>
+// NB batch items of one (column, tile, group, out-chunk) share a workgroup and with it every
+// kernel-spectrum load of the mix (the spectrum of a column is cob x Cig x T complex, several times
+// the signal data of one batch item; streaming it per batch item bound this kernel).
+template <int P, int S, int CIB, int NB, int NT>
 __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
   constexpr int LSEQP = SeqLayout<G>::LSEQP;
-  static_assert(NT == CIB * G::TS, "one sequence per channel of the chunk");
+  constexpr int NSEQ = NB * CIB;
+  static_assert(NT == NSEQ * G::TS, "one sequence per channel of the chunk and batch slot");
+  constexpr int R = NT > T ? NT / T : 1;                // mix threads per bin (they split the output channels)
+  constexpr int BPT = NT > T ? 1 : T / NT;              // bins per mix thread
+  static_assert(R * T == NT || BPT * NT == T, "threads and bins divide evenly");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int nbi = sq / CIB, ch = sq % CIB;              // batch slot, channel slot
 
   // XCD-aware unit map.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 shares an L2), and
-  // a column's kernel spectrum (Cog x Cig x T complex, e.g. 256 KB) is read by every batch item of
-  // that column: so the column is tied to id % 8 and the batch index runs fastest behind it --
-  // all B workgroups of a column hit the same L2 back to back and the spectrum leaves the
+  // a column's kernel spectrum (Cog x Cig x T complex, e.g. 256 KB) is read by every batch block of
+  // that column: so the column is tied to id % 8 and the batch block runs fastest behind it --
+  // all workgroups of a column hit the same L2 back to back and the spectrum leaves the
   // Infinity Cache once per XCD instead of once per workgroup.
-  //   id = ((((tile*n_ochunks + oc)*G + g)*ncb + colblk)*B + b)*8 + xcd ,  col = colblk*8 + xcd
+  //   id = ((((tile*n_ochunks + oc)*G + g)*ncb + colblk)*nbb + bb)*8 + xcd ,  col = colblk*8 + xcd
   int id = blockIdx.x;
   const int xcd = id & 7; id >>= 3;
-  const int b = id % a.B; id /= a.B;
+  const int nbb = (a.B + NB - 1) / NB;
+  const int b0 = (id % nbb) * NB; id /= nbb;
   const int ncb = (a.ncol + 7) >> 3;
   const int col = (id % ncb) * 8 + xcd; id /= ncb;
   const int g = id % a.G; id /= a.G;
   const int oc = id % a.n_ochunks;
   const int tile = id / a.n_ochunks;
   if (col >= a.ncol) return;                 // padding of the last column block (uniform per workgroup)
+  const int nbc = min(NB, a.B - b0);         // batch items of this workgroup
+  auto stampc = [&](int slot) {
+    if (a.stamps != nullptr && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+  };
+  stampc(0);
 
   f2* zin = lds;
-  f2* vout = a.accumulate ? lds + CIB * LSEQP : lds;
+  f2* vout = a.accumulate ? lds + NSEQ * LSEQP : lds;
   const int n_ichunks = a.Cig_pad / CIB;
   const int t0 = tile * a.V;
   const size_t wcol = (size_t)a.ncol * T;                          // f4 per (o, ip)
@@ -437,79 +449,107 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
 
   for (int ic = 0; ic < n_ichunks; ++ic) {
     {
-      const int ci = ic * CIB + sq;
-      const bool has = ci < a.Cig;
-      const f2* s = a.src + (((size_t)b * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
+      const int ci = ic * CIB + ch;
+      const bool has = ci < a.Cig && nbi < nbc;
+      const f2* s = a.src + (((size_t)(b0 + (has ? nbi : 0)) * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
       f2 v[P];
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
         const int n = G::N2 * n1 + tseq;
         v[n1] = (has && t0 + n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
       }
+      if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampc(1); }
       fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA, twB);
     }
+    stampc(2);
     __syncthreads();
+    stampc(3);
     // mix: every bin is independent in complex mode.  step = (bin of this thread, output channel o);
     // two register sets alternate so the CIB/2 spectrum loads of the next step are in flight while
-    // this one is contracted (same scheme as the 1-D kernel).
+    // this one is contracted for all NB batch items (same scheme as the 1-D kernel).
     {
-      constexpr int BPT = (T + NT - 1) / NT;              // bins per thread
       constexpr int NH = CIB / 2;
-      const int nsteps = BPT * a.cob;
+      const int h = R > 1 ? tid / T : 0;                  // which share of the output channels
+      const int f0 = R > 1 ? tid % T : tid;
+      const int no = R > 1 ? (a.cob - h + R - 1) / R : a.cob;      // outputs o = h + R*k, k < no
+      const int nsteps = BPT * max(no, 0);
       const size_t orow = (size_t)(a.Cig_pad / 2) * wcol;  // float4 between output channels
-      const f4* wbase = wgrp + ((size_t)(oc * a.cob) * (a.Cig_pad / 2) + ic * NH) * wcol;
+      const f4* wbase = wgrp + ((size_t)(oc * a.cob + h) * (a.Cig_pad / 2) + ic * NH) * wcol;
       f4 wA[NH], wB[NH];
-      f2 x[CIB];
-      auto issue = [&](int m, int o, f4 (&dst)[NH]) {
-        const int f = min(tid + m * NT, T - 1);
-        const f4* w = wbase + (size_t)o * orow + f;
+      f2 x[NB][CIB];
+      auto issue = [&](int m, int k, f4 (&dst)[NH]) {
+        const int f = f0 + m * NT;
+        const f4* w = wbase + (size_t)(R * k) * orow + f;
 #pragma unroll
         for (int p = 0; p < NH; ++p) dst[p] = w[(size_t)p * wcol];
       };
-      auto step = [&](int m, int o, const f4 (&wc)[NH]) {
-        const int f = tid + m * NT;
-        const bool live = f < T;
-        const int fc = live ? f : 0;
-        if (o == 0) {
+      auto load_x = [&](int m) {
+        const unsigned base = lds_off(zin + G::nat(f0 + m * NT));
+        static_for<0, NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          const unsigned bb = base + b * CIB * LSEQP * 8;
+          static_for<0, CIB>([&](auto icn) {
+            constexpr int i = decltype(icn)::value;
+            x[b][i] = lds_rd_far<i * LSEQP * 8>(bb);
+          });
+        });
 #pragma unroll
-          for (int i = 0; i < CIB; ++i) x[i] = zin[i * LSEQP + G::nat(fc)];
-        }
-        f2 y = mk2(0.f, 0.f);
+        for (int b = 0; b < NB; ++b) lds_arrive(x[b]);
+      };
+      auto step = [&](int m, int k, const f4 (&wc)[NH]) {
+        const int o = h + R * k;
+        const int f = f0 + m * NT;
 #pragma unroll
-        for (int p = 0; p < NH; ++p) {
-          cmac(y, x[2 * p], wc[p].xy);
-          cmac(y, x[2 * p + 1], wc[p].zw);
-        }
-        if (live) {
-          f2* pv = vout + o * LSEQP + G::nat(fc);
-          if (ic != 0) y += *pv;
-          *pv = y;
+        for (int b = 0; b < NB; ++b) {
+          f2 y = mk2(0.f, 0.f);
+#pragma unroll
+          for (int p = 0; p < NH; ++p) {
+            cmac(y, x[b][2 * p], wc[p].xy);
+            cmac(y, x[b][2 * p + 1], wc[p].zw);
+          }
+          if (b < nbc) {
+            f2* pv = vout + (b * CIB + o) * LSEQP + G::nat(f);
+            if (ic != 0) y += *pv;
+            *pv = y;
+          }
         }
       };
-      int m = 0, o = 0;
-      issue(0, 0, wA);
+      if (nsteps > 0) issue(0, 0, wA);
+      if (R > 1) {
+        // several threads (in different waves) read a bin that others overwrite in place
+        load_x(0);
+        __syncthreads();
+      }
+      int m = 0, k = 0;
 #pragma unroll 1
       for (int s2 = 0; s2 < nsteps; s2 += 2) {
-        int o1 = o + 1, m1 = m;
-        if (o1 == a.cob) { o1 = 0; ++m1; }
-        int o2 = o1 + 1, m2 = m1;
-        if (o2 == a.cob) { o2 = 0; ++m2; }
-        if (s2 + 1 < nsteps) issue(m1, o1, wB);
-        step(m, o, wA);
-        if (s2 + 2 < nsteps) issue(m2, o2, wA);
-        if (s2 + 1 < nsteps) step(m1, o1, wB);
-        m = m2; o = o2;
+        int k1 = k + 1, m1 = m;
+        if (k1 == no) { k1 = 0; ++m1; }
+        int k2 = k1 + 1, m2 = m1;
+        if (k2 == no) { k2 = 0; ++m2; }
+        if (s2 + 1 < nsteps) issue(m1, k1, wB);
+        if (R == 1 && k == 0) load_x(m);
+        step(m, k, wA);
+        if (s2 + 2 < nsteps) issue(m2, k2, wA);
+        if (s2 + 1 < nsteps) {
+          if (R == 1 && k1 == 0) load_x(m1);
+          step(m1, k1, wB);
+        }
+        m = m2; k = k2;
       }
     }
+    stampc(4);
     __syncthreads();
+    stampc(5);
   }
   // inverse + store of the valid, decimated samples
   f2 v[P];
-  const bool act = sq < a.cob;
+  const bool act = ch < a.cob && nbi < nbc;
   const int j = inv_to_regs<G>(v, vout + sq * LSEQP, tseq, act, twA, twB);
-  const int co = oc * a.cob + sq;
+  stampc(6);
+  const int co = oc * a.cob + ch;
   if (act && co < a.Cog) {
-    f2* out = a.dst + (((size_t)b * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
+    f2* out = a.dst + (((size_t)(b0 + nbi) * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
     const int limit = min(a.V, a.Lfull - t0);
     const int nbase = (tseq >> G::LGS) + P * P * j;
 #pragma unroll
@@ -520,6 +560,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
       if (n < limit && idx * a.stride == t) out[idx] = v[k];
     }
   }
+  if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampc(7); }
 }
 
 }  // namespace fc

@@ -109,22 +109,46 @@ hipError_t rows_c2r_dispatch(const RowsC2RArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-template <int CIB>
-hipError_t launch_fusedc(const FusedCArgs& a, hipStream_t st) {
-  if constexpr (CIB > kFusedMaxCib) {
+// fused column pass: NB batch items per workgroup share the spectrum loads.  NB is the largest of
+// {4, 2, 1} that fits the batch, 1024 threads, the 160 KiB of LDS and 32 spectrum values per mix
+// thread, and still leaves two workgroups per CU's worth of grid.
+template <int CIB, int NB>
+constexpr bool fusedc_fits() {
+  return CIB <= kFusedMaxCib && NB * CIB * GG::TS <= 1024 && NB * CIB <= 32 &&
+         (size_t)NB * CIB * kLSEQP * sizeof(float2) <= 160 * 1024;
+}
+template <int CIB, int NB>
+hipError_t launch_fusedc_nb(const FusedCArgs& a, hipStream_t st) {
+  if constexpr (!fusedc_fits<CIB, NB>()) {
     return hipErrorInvalidValue;
   } else {
-    constexpr int NT = CIB * GG::TS;
-    auto k = fusedc_kernel<FC_P, FC_S, CIB, NT>;
-    const size_t lds = (size_t)(a.accumulate ? 2 : 1) * CIB * kLSEQP * sizeof(float2);
+    constexpr int NT = NB * CIB * GG::TS;
+    auto k = fusedc_kernel<FC_P, FC_S, CIB, NB, NT>;
+    const size_t lds = (size_t)(a.accumulate ? 2 : 1) * NB * CIB * kLSEQP * sizeof(float2);
     static bool done = false;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;
-    const long long grid = (long long)a.B * a.ntiles * a.n_ochunks * a.G * ((a.ncol + 7) / 8) * 8;
+    const long long nbb = (a.B + NB - 1) / NB;
+    const long long grid = nbb * a.ntiles * a.n_ochunks * a.G * ((a.ncol + 7) / 8) * 8;
     if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
     return hipGetLastError();
   }
+}
+template <int CIB>
+hipError_t launch_fusedc(const FusedCArgs& a, hipStream_t st) {
+  auto ok = [&](int nb, bool fits) {
+    if (!fits || nb > a.B) return false;
+    const size_t lds = (size_t)(a.accumulate ? 2 : 1) * nb * CIB * kLSEQP * sizeof(float2);
+    const long long grid = (long long)((a.B + nb - 1) / nb) * a.ntiles * a.n_ochunks * a.G * a.ncol;
+    return lds <= 160 * 1024 && (nb == 1 || grid >= 512);
+  };
+  static const int force = getenv("FFTCONV_FUSEDC_NB") ? atoi(getenv("FFTCONV_FUSEDC_NB")) : 0;   // tuning knob
+  if (force != 1) {
+    if ((force == 0 || force == 4) && ok(4, fusedc_fits<CIB, 4>())) return launch_fusedc_nb<CIB, 4>(a, st);
+    if ((force == 0 || force == 2) && ok(2, fusedc_fits<CIB, 2>())) return launch_fusedc_nb<CIB, 2>(a, st);
+  }
+  return launch_fusedc_nb<CIB, 1>(a, st);
 }
 
 hipError_t fusedc_dispatch(int cib, const FusedCArgs& a, hipStream_t st) {

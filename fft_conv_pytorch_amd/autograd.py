@@ -23,7 +23,8 @@ from torch import Tensor
 
 from . import functional as F_
 
-_MAX_KERNEL_EXTENT = 2048      # dilated extent of kernel' that still leaves a useful valid window in a 4096 tile
+_DW_TILE = 2048      # FFT tile the dW correlation is sized for: the largest one that also fits the
+                     # accumulating (> 8 channels', i.e. batch > 8) mode of the fused kernel in LDS
 
 
 def _grad_input(grad: Tensor, weight: Tensor, in_spatial, stride, padding, dilation, groups, padding_mode) -> Tensor:
@@ -57,12 +58,16 @@ def _grad_weight_group(x: Tensor, grad: Tensor, ksize, stride, padding, dilation
     xt = x.transpose(0, 1).contiguous()          # (Ci, B, *S)   : batch' = Ci, channels' = B
     gt = grad.transpose(0, 1).contiguous()       # (Co, B, *Lout): out' = Co,  in' = B
     kext = [(grad.shape[2 + i] - 1) * stride[i] + 1 for i in range(n)]
-    if n == 1 and kext[0] > _MAX_KERNEL_EXTENT:
+    kd0 = (ksize[0] - 1) * dilation[0] + 1
+    # one overlap-save tile must hold kernel' (extent kext) plus the kd - 1 further samples that give the
+    # k taps of dW; a longer gradient would leave the tile (almost) no valid window (V = T - kext + 1)
+    max_ext = max(_DW_TILE - kd0 + 1, _DW_TILE // 4)
+    if n == 1 and kext[0] > max_ext:
         # Long rows: kernel' (the gradient) is cut into chunks of C taps; chunk j only meets the signal
         # window [j*C*s - p, j*C*s - p + (C-1)*s + 1 + Kd - 1).  Chunks ride the group axis.
         s, p, d = stride[0], padding[0], dilation[0]
-        kd = (ksize[0] - 1) * d + 1
-        c_taps = max(1, (_MAX_KERNEL_EXTENT - 1) // s + 1)
+        kd = kd0
+        c_taps = max(1, (max_ext - 1) // s + 1)
         lout = grad.shape[2]
         nchunk = (lout + c_taps - 1) // c_taps
         seg = (c_taps - 1) * s + kd                                  # signal samples one chunk needs

@@ -194,7 +194,7 @@ static int plan_1d(fc_plan* p) {
 
 static bool fast_path_eligible(const fc_plan* p) {
   const fc_desc& d = p->d;
-  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1 || d.transposed) return false;
+  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1) return false;   // (a transposed plan with stride 1 is a padded correlation: same kernel)
   if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return false;
   return true;
 }

@@ -21,7 +21,7 @@ ABI_VERSION = 2
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
     "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_transform_kernel", "fc_forward",
-    "fc_debug_set_stamps", "fc_debug_grid",
+    "fc_wgrad1d_slices", "fc_wgrad1d", "fc_debug_set_stamps", "fc_debug_grid",
 )
 
 
@@ -79,6 +79,10 @@ def load_library() -> ctypes.CDLL:
         lib.fc_transform_kernel.restype = i32
         lib.fc_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp]
         lib.fc_forward.restype = i32
+        lib.fc_wgrad1d_slices.argtypes = [ctypes.POINTER(FcDesc)]
+        lib.fc_wgrad1d_slices.restype = i32
+        lib.fc_wgrad1d.argtypes = [ctypes.POINTER(FcDesc), vp, vp, vp, i32, vp]
+        lib.fc_wgrad1d.restype = i32
         lib.fc_debug_set_stamps.argtypes = [vp, vp]
         lib.fc_debug_set_stamps.restype = i32
         lib.fc_debug_grid.argtypes = [vp]
@@ -87,6 +91,34 @@ def load_library() -> ctypes.CDLL:
             raise ImportError(f"{LIB_NAME}: ABI version {lib.fc_version()} != {ABI_VERSION}")
         _lib = lib
     return _lib
+
+
+def conv_desc(ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode) -> FcDesc:
+    """``struct fc_desc`` of a forward convolution (used by the calls that take a descriptor, not a plan)."""
+    d = FcDesc()
+    d.ndim, d.dtype = ndim, 0
+    d.batch, d.in_channels, d.out_channels, d.groups = batch, cin, cout, groups
+    for i in range(3):
+        d.spatial[i] = spatial[i] if i < ndim else 1
+        d.kernel[i] = kernel[i] if i < ndim else 1
+        d.stride[i] = stride[i] if i < ndim else 1
+        d.padding[i] = padding[i] if i < ndim else 0
+        d.dilation[i] = dilation[i] if i < ndim else 1
+        d.output_padding[i] = 0
+    d.padding_mode, d.has_bias, d.tile_hint, d.transposed = mode, 0, 0, 0
+    return d
+
+
+def wgrad1d_slices(desc: FcDesc) -> int:
+    """Partial-result count of ``fc_wgrad1d`` for this shape on the current device; 0 = not covered."""
+    return int(load_library().fc_wgrad1d_slices(ctypes.byref(desc)))
+
+
+def wgrad1d(desc: FcDesc, x_ptr: int, dy_ptr: int, partial_ptr: int, slices: int, stream: int):
+    lib = load_library()
+    st = lib.fc_wgrad1d(ctypes.byref(desc), x_ptr, dy_ptr, partial_ptr, slices, stream)
+    if st != FC_OK:
+        _raise(lib, st)
 
 
 def _raise(lib, status: int):

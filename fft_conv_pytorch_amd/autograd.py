@@ -5,9 +5,10 @@ The reference has no custom backward: autograd differentiates its rfftn/einsum/i
 autograd, so the three gradients are expressed as convolutions the native library already runs:
 
     dX = conv_transpose(dY, W)             -> ``fc_forward`` on a transposed plan
-    dW = correlate(X, dY) over the batch   -> ``fc_forward`` with the roles of batch and channels
-                                              swapped: signal' = X^T (Cin/g, B, *S), kernel' = dY^T
-                                              (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;
+    dW = correlate(X, dY) over the batch   -> 1-D, stride 1, <= 8 channels per group: ``fc_wgrad1d`` (cross-spectra
+                                              accumulated on chip); otherwise ``fc_forward`` with the roles of
+                                              batch and channels swapped: signal' = X^T (Cin/g, B, *S), kernel' =
+                                              dY^T (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;
                                               long 1-D rows are cut into chunks that ride the group axis
     db = sum of dY over batch and space    -> a plain reduction
 
@@ -55,8 +56,6 @@ def _grad_weight_group(x: Tensor, grad: Tensor, ksize, stride, padding, dilation
     """dW of one channel group.  x: (B, Ci, *S), grad: (B, Co, *Lout) -> (Co, Ci, *k)."""
     n = x.ndim - 2
     b = x.shape[0]
-    xt = x.transpose(0, 1).contiguous()          # (Ci, B, *S)   : batch' = Ci, channels' = B
-    gt = grad.transpose(0, 1).contiguous()       # (Co, B, *Lout): out' = Co,  in' = B
     kext = [(grad.shape[2 + i] - 1) * stride[i] + 1 for i in range(n)]
     kd0 = (ksize[0] - 1) * dilation[0] + 1
     # one overlap-save tile must hold kernel' (extent kext) plus the kd - 1 further samples that give the
@@ -71,25 +70,52 @@ def _grad_weight_group(x: Tensor, grad: Tensor, ksize, stride, padding, dilation
         lout = grad.shape[2]
         nchunk = (lout + c_taps - 1) // c_taps
         seg = (c_taps - 1) * s + kd                                  # signal samples one chunk needs
-        flat = [p, p] if p else None
-        xp = F.pad(xt, flat, mode=padding_mode) if flat else xt      # (Ci, B, S+2p)
+        # one padded copy of each operand, then one gather through an overlapping strided view
         need = (nchunk - 1) * c_taps * s + seg
-        if xp.shape[-1] < need:
-            xp = F.pad(xp, [0, need - xp.shape[-1]])
-        win = xp.unfold(-1, seg, c_taps * s)[:, :, :nchunk]          # (Ci, B, nchunk, seg)
-        sig = win.permute(0, 2, 1, 3).reshape(xt.shape[0], nchunk * b, seg).contiguous()
-        gpad = F.pad(gt, [0, nchunk * c_taps - lout])                # (Co, B, nchunk*C)
-        ker = gpad.reshape(gt.shape[0], b, nchunk, c_taps).permute(2, 0, 1, 3).reshape(nchunk * gt.shape[0], b, c_taps)
+        if padding_mode == "constant" or p == 0:
+            xp = F.pad(x, [p, max(0, need - x.shape[-1] - p)])       # (B, Ci, >= need)
+        else:
+            xp = F.pad(x, [p, p], mode=padding_mode)
+            if xp.shape[-1] < need:
+                xp = F.pad(xp, [0, need - xp.shape[-1]])
+        sb, sc, sl = xp.stride()
+        sig = xp.as_strided((x.shape[1], nchunk, b, seg), (sc, c_taps * s * sl, sb, sl)).reshape(x.shape[1], nchunk * b, seg)
+        gp = F.pad(grad, [0, nchunk * c_taps - lout])                # (B, Co, nchunk*C)
+        gb, gc, gl = gp.stride()
+        ker = gp.as_strided((nchunk, grad.shape[1], b, c_taps), (c_taps * gl, gc, gb, gl)).reshape(nchunk * grad.shape[1], b, c_taps)
         part = F_.fft_conv(sig, ker.contiguous(), None, stride=d, padding=0, dilation=s, groups=nchunk)
-        part = part.reshape(xt.shape[0], nchunk, gt.shape[0], -1).sum(dim=1)      # (Ci, Co, >=k)
+        part = part.reshape(x.shape[1], nchunk, grad.shape[1], -1).sum(dim=1)      # (Ci, Co, >=k)
         return part[..., : ksize[0]].permute(1, 0, 2).contiguous()
+    xt = x.transpose(0, 1).contiguous()          # (Ci, B, *S)   : batch' = Ci, channels' = B
+    gt = grad.transpose(0, 1).contiguous()       # (Co, B, *Lout): out' = Co,  in' = B
     out = F_.fft_conv(xt, gt, None, stride=dilation, padding=padding, dilation=stride, groups=1,
                       padding_mode=padding_mode)                    # (Ci, Co, >= k per axis)
     index = (slice(None), slice(None)) + tuple(slice(0, k) for k in ksize)
     return out[index].transpose(0, 1).contiguous()
 
 
+def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode):
+    """dW by ``fc_wgrad1d`` (cross-spectra accumulated on chip over batch and row); None when not covered."""
+    if x.ndim != 3:
+        return None
+    from . import _native
+    desc = _native.conv_desc(1, x.shape[0], x.shape[1], wshape[0], groups, (x.shape[2],), (wshape[2],), stride, padding,
+                             dilation, _native.PAD_MODES[padding_mode])
+    slices = _native.wgrad1d_slices(desc)
+    if slices == 0:
+        return None
+    x = x.contiguous()
+    grad = grad.contiguous()
+    part = torch.empty((slices,) + tuple(wshape), device=x.device, dtype=torch.float32)
+    _native.wgrad1d(desc, x.data_ptr(), grad.data_ptr(), part.data_ptr(), slices,
+                    torch.cuda.current_stream(x.device).cuda_stream)
+    return part[0] if slices == 1 else part.sum(dim=0)
+
+
 def _grad_weight(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
+    native = _grad_weight_native(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
+    if native is not None:
+        return native
     cout, cig = wshape[0], wshape[1]
     cog = cout // groups
     parts = []

@@ -488,6 +488,73 @@ size_t fc_kernel_spectrum_bytes(const fc_plan* plan) { return plan ? plan->spect
 size_t fc_workspace_bytes(const fc_plan* plan) { return plan ? plan->workspace_bytes : 0; }
 int fc_plan_tile(const fc_plan* plan) { return plan && plan->tile ? plan->tile->T : 0; }
 
+// ---- 1-D weight gradient
+namespace {
+struct WgradGeom { const fc::TileImpl* t; int kd, V, ntiles, nob, nib, Cig, Cog, n_items, ipw, slices, pad; };
+int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
+  if (d.ndim != 1 || d.dtype != FC_F32 || d.transposed || d.stride[0] != 1 || d.groups < 1) return 0;
+  if (d.batch < 1 || d.in_channels % d.groups || d.out_channels % d.groups) return 0;
+  const int64_t Cig = d.in_channels / d.groups, Cog = d.out_channels / d.groups;
+  if (Cig > 8 || Cog > 8) return 0;
+  const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
+  const fc::TileImpl* t = find_tile(1024);
+  if (!t || !t->wgrad1d || kd > 768 || d.padding[0] < 0) return 0;
+  const int64_t Lout = d.spatial[0] + 2 * d.padding[0] - kd + 1;
+  if (Lout < 1) return 0;
+  if (d.padding_mode == FC_PAD_REFLECT && d.padding[0] >= d.spatial[0]) return 0;
+  if (d.padding_mode == FC_PAD_CIRCULAR && d.padding[0] > d.spatial[0]) return 0;
+  if ((int64_t)d.batch * d.in_channels * d.spatial[0] * 4 >= ((int64_t)1 << 32) ||
+      (int64_t)d.batch * d.out_channels * Lout * 4 >= ((int64_t)1 << 32)) return 0;
+  const int64_t V = t->T - kd + 1, ntiles = (Lout + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
+  if (n_items > 0x3fffffff) return 0;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  const int nb = t->wgrad_nb;
+  g->t = t; g->kd = (int)kd; g->V = (int)V; g->ntiles = (int)ntiles; g->Cig = (int)Cig; g->Cog = (int)Cog;
+  g->nob = (int)(Cog + 3) / 4; g->nib = (int)(Cig + 3) / 4; g->n_items = (int)n_items; g->pad = (int)d.padding[0];
+  const int64_t types = (int64_t)d.groups * g->nob * g->nib;
+  // two workgroups per CU; every slice costs one inverse transform and one partial result, so a slice
+  // gets at least 4 iterations of work
+  int64_t slices = std::max<int64_t>(1, (2 * (int64_t)cus + types - 1) / types);
+  slices = std::min<int64_t>(slices, std::max<int64_t>(1, n_items / (4 * nb)));
+  int64_t ipw = (n_items + slices - 1) / slices;
+  ipw = (ipw + nb - 1) / nb * nb;
+  g->ipw = (int)ipw;
+  g->slices = (int)((n_items + ipw - 1) / ipw);
+  return 1;
+}
+}  // namespace
+
+int fc_wgrad1d_slices(const fc_desc* desc) {
+  if (!desc) return 0;
+  WgradGeom g;
+  return wgrad_geometry(*desc, &g) ? g.slices : 0;
+}
+
+int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream) {
+  if (!desc || !x || !dy || !partial) return fail(FC_ERR_INVALID, "null argument");
+  WgradGeom g;
+  if (!wgrad_geometry(*desc, &g)) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad1d does not cover this shape");
+  if (slices != g.slices) return fail(FC_ERR_INVALID, "partial holds %d slices, the plan needs %d", slices, g.slices);
+  Twiddles tw;
+  int rc = get_twiddles(g.t, &tw);
+  if (rc != FC_OK) return rc;
+  const fc_desc& d = *desc;
+  fc::WGradArgs a;
+  a.x = x; a.dy = dy; a.part = partial; a.twA = tw.twA; a.twB = tw.twB;
+  a.B = (int)d.batch; a.Cin = (int)d.in_channels; a.Cout = (int)d.out_channels; a.G = (int)d.groups;
+  a.Cig = g.Cig; a.Cog = g.Cog; a.L = (int)d.spatial[0]; a.pad = g.pad; a.pad_mode = d.padding_mode;
+  a.Lout = (int)(d.spatial[0] + 2 * d.padding[0] - g.kd + 1);
+  a.K = (int)d.kernel[0]; a.dil = (int)d.dilation[0]; a.V = g.V; a.ntiles = g.ntiles;
+  a.n_items = g.n_items; a.items_per_slice = g.ipw; a.nob = g.nob; a.nib = g.nib;
+  a.scale = 1.0f / (4.0f * (float)g.t->T);
+  const int64_t grid = (int64_t)g.slices * d.groups * g.nob * g.nib;
+  if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
+  FC_HIP(g.t->wgrad1d(a, (int)grid, (hipStream_t)hip_stream));
+  return FC_OK;
+}
+
 int fc_debug_set_stamps(fc_plan* plan, void* device_buffer) {
   if (!plan) return fail(FC_ERR_INVALID, "null argument");
   plan->debug_stamps = device_buffer;

@@ -5,6 +5,7 @@
 #include "conv1d_pers.hpp"
 #include "nd_passes.hpp"
 #include "spectrum1d.hpp"
+#include "wgrad1d.hpp"
 
 namespace fc {
 
@@ -27,6 +28,9 @@ struct TileImpl {
   int pers_nb[2];        // supported nb values (0 = none)
   size_t pers_lds[2];    // LDS bytes for each
   int pers_nt[2];
+  // 1-D weight gradient (wgrad1d.hpp), built for the 1024-point tile only (else null)
+  hipError_t (*wgrad1d)(const WGradArgs& a, int grid, hipStream_t st);
+  int wgrad_nb;          // items per iteration of that kernel
 };
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();

@@ -193,6 +193,22 @@ hipError_t pers_dispatch(int nb, const Conv1dPersArgs& a, int grid, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+#if FC_P == 32 && FC_S == 1
+constexpr int kWgradNb = 2;
+hipError_t wgrad_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
+  constexpr int NT = kWgradNb * 4 * GG::TS;
+  auto k = wgrad1d_kernel<FC_P, FC_S, kWgradNb, NT>;
+  const size_t lds = ((size_t)FC_P * GG::N2 + (size_t)kWgradNb * 4 * GG::LSEQ) * sizeof(float2);
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+#else
+constexpr int kWgradNb = 0;
+#endif
+
 }  // namespace
 
 #define FC_CAT_(a, b, c, d) a##b##c##d
@@ -203,7 +219,13 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
                                 c2c_dispatch<true>, rows_c2r_dispatch, fusedc_dispatch, kFusedMaxCib,
                                 pers_dispatch, {kPersNb0, kPersNb1},
                                 {kPersNb0 ? pers_lds_bytes(kPersNb0) : 0, kPersNb1 ? pers_lds_bytes(kPersNb1) : 0},
-                                {kPersNb0 * 4 * GG::TS, kPersNb1 * 4 * GG::TS}};
+                                {kPersNb0 * 4 * GG::TS, kPersNb1 * 4 * GG::TS},
+#if FC_P == 32 && FC_S == 1
+                                wgrad_dispatch,
+#else
+                                nullptr,
+#endif
+                                kWgradNb};
   return &impl;
 }
 

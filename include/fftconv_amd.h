@@ -94,6 +94,18 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
 int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
                void* workspace, void* hip_stream);
 
+/* Weight gradient of the 1-D convolution described by `desc` (the FORWARD descriptor):
+ *   dW[o][i][k] = sum_b sum_t dY[b][o][t] * pad(x)[b][i][t + k*dilation]
+ * i.e. what autograd derives from functional.py:60-87 for `kernel` (pinned by the reference's
+ * tests/test_functional.py:111-117).  Covered: ndim 1, stride 1, <= 8 channels per group on both
+ * sides, dilated kernel extent <= 768, any padding mode.  Cross-spectra are accumulated over the batch
+ * and the row on chip; the result comes in `slices` partial tensors that the caller sums:
+ *   partial is (slices, Cout, Cin/groups, K) fp32, fully written by the call.
+ * fc_wgrad1d_slices returns the slice count for the current device, 0 when the shape is not covered
+ * (the caller then differentiates through fc_forward plans instead). */
+int fc_wgrad1d_slices(const fc_desc* desc);
+int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream);
+
 /* Profiling hook (not part of the drop-in surface): when a device buffer of
  * 16 * fc_debug_grid(plan) uint64 is set, lane 0 of every workgroup of the fused
  * 1-D kernel stores the 100 MHz wall clock at its phase boundaries.  NULL = off. */

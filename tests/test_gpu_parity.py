@@ -293,3 +293,37 @@ def test_backward_long_rows_and_padding_modes(mode):
     ref(xc).backward(gy)
     for got, want in ((xd.grad, xc.grad), (layer.weight.grad, ref.weight.grad), (layer.bias.grad, ref.bias.grad)):
         assert (got.cpu() - want).abs().max().item() / want.abs().max().item() < REL_TOL
+
+
+WGRAD_CASES = [  # B, Cin, Cout, groups, L, K, padding, dilation, mode
+    (32, 8, 8, 1, 32768, 512, 0, 1, "constant"),      # cfgA
+    (3, 3, 5, 1, 2000, 17, 8, 1, "constant"),         # odd channel counts inside one 4 x 4 block pair
+    (1, 8, 8, 1, 700, 33, 0, 3, "constant"),          # single tile, dilation 3
+    (5, 16, 24, 4, 5000, 129, 64, 2, "reflect"),      # groups, 4 in / 6 out per group
+    (2, 6, 6, 2, 4096, 1, 0, 1, "constant"),          # 1-tap kernel
+    (7, 8, 8, 1, 3000, 385, 100, 2, "circular"),      # dilated extent 769 > 768: falls back to the plan path
+    (4, 7, 8, 1, 1500, 200, 30, 1, "replicate"),
+    (9, 8, 8, 8, 10000, 65, 5, 1, "constant"),        # depthwise-like: one channel per group
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_weight_gradient_kernel(case):
+    """fc_wgrad1d (cross-spectra accumulated on chip) against autograd through torch's direct convolution in
+    float64; shapes it does not cover must come back through the plan-based path with the same result."""
+    from fft_conv_pytorch_amd import autograd as ag
+    B, cin, cout, groups, L, K, pad, dil, mode = case
+    gen = torch.Generator().manual_seed(1234 + L)
+    x = torch.randn(B, cin, L, generator=gen)
+    w = torch.randn(cout, cin // groups, K, generator=gen, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(x.double(), [pad, pad], mode=mode) if (mode != "constant" and pad) else x.double()
+    y = F.conv1d(xp, w, None, padding=pad if mode == "constant" else 0, dilation=dil, groups=groups)
+    gy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    (want,) = torch.autograd.grad(y, w, gy)
+    got = ag._grad_weight(x.to(DEV), gy.float().to(DEV), tuple(w.shape), (1,), (pad,), (dil,), groups, mode)
+    covered = ag._grad_weight_native(x.to(DEV), gy.float().to(DEV), tuple(w.shape), (1,), (pad,), (dil,), groups, mode)
+    assert (covered is None) == ((K - 1) * dil + 1 > 768)
+    assert got.shape == want.shape
+    err = (got.double().cpu() - want).norm().item() / want.norm().item()
+    print(f"wgrad {case}: rel err {err:.2e}")
+    assert err < REL_TOL

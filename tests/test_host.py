@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     from fft_conv_pytorch_amd import _native
     lib = _native.load_library()
     header = open(os.path.join(ROOT, "include", "fftconv_amd.h")).read()
-    declared = set(re.findall(r"\b(fc_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(fc_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations found"
     assert declared == set(_native.EXPORTS)
     for sym in declared:

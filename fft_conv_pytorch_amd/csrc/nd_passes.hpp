@@ -337,18 +337,43 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   {
     // rows 2s (-> real part) and 2s+1 (-> imaginary part) share one complex inverse FFT:
     // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
+    // Four bins per thread are requested before any is consumed (the loop is latency-bound otherwise);
+    // a row pair is one 16-byte load when it is whole and aligned.
     const f2* in = a.src + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
-    for (int idx = tid; idx < a.Fx * NSEQ; idx += NT) {
-      const int s = idx % NSEQ, fx = idx / NSEQ;
-      f2 ya = mk2(0.f, 0.f), yb2 = mk2(0.f, 0.f);
-      if (y0 + 2 * s < a.NY) ya = in[(size_t)fx * a.NYa + 2 * s];
-      if (y0 + 2 * s + 1 < a.NY) yb2 = in[(size_t)fx * a.NYa + 2 * s + 1];
-      f2* z = lds + s * LSEQP;
-      if (fx == 0 || fx == T / 2) {
-        z[G::nat(fx)] = mk2(ya.x, yb2.x);          // both spectra are real at the self-paired bins
-      } else {
-        z[G::nat(fx)] = mk2(ya.x - yb2.y, ya.y + yb2.x);
-        z[G::nat(T - fx)] = mk2(ya.x + yb2.y, yb2.x - ya.y);
+    const int total = a.Fx * NSEQ;
+    const bool pair16 = ((a.NYa | y0) & 1) == 0;
+    constexpr int U = 4;
+    for (int base = 0; base < total; base += U * NT) {
+      f2 ya[U], yb2[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * NT + tid;
+        const int s = idx % NSEQ, fx = idx / NSEQ;
+        ya[u] = mk2(0.f, 0.f); yb2[u] = mk2(0.f, 0.f);
+        if (idx < total) {
+          const f2* p = in + (size_t)fx * a.NYa + 2 * s;
+          if (pair16 && y0 + 2 * s + 1 < a.NY) {
+            const f4 q = *reinterpret_cast<const f4*>(p);
+            ya[u] = q.xy; yb2[u] = q.zw;
+          } else {
+            if (y0 + 2 * s < a.NY) ya[u] = p[0];
+            if (y0 + 2 * s + 1 < a.NY) yb2[u] = p[1];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = base + u * NT + tid;
+        if (idx < total) {
+          const int s = idx % NSEQ, fx = idx / NSEQ;
+          f2* z = lds + s * LSEQP;
+          if (fx == 0 || fx == T / 2) {
+            z[G::nat(fx)] = mk2(ya[u].x, yb2[u].x);          // both spectra are real at the self-paired bins
+          } else {
+            z[G::nat(fx)] = mk2(ya[u].x - yb2[u].y, ya[u].y + yb2[u].x);
+            z[G::nat(T - fx)] = mk2(ya[u].x + yb2[u].y, yb2[u].x - ya[u].y);
+          }
+        }
       }
     }
   }

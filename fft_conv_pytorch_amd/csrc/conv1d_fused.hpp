@@ -40,7 +40,6 @@ struct Conv1dArgs {
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
-  int delay_from, delay_ticks; // experiment: workgroups >= delay_from start delay_ticks (10 ns units) late
 };
 
 // Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with
@@ -129,10 +128,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
 
-  if (a.delay_ticks > 0 && (int)blockIdx.x >= a.delay_from && (int)blockIdx.x < 2 * a.delay_from) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)a.delay_ticks) __builtin_amdgcn_s_sleep(8);
-  }
   stamp(a.stamps, 0);
   for (int ic = 0; ic < n_ichunks; ++ic) {
     // ------------------------------------------------ forward pass A (global -> regs -> LDS)

@@ -32,7 +32,7 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT, int MIXDEPTH = 4>
+template <int P, int S, int CIB, int NB, int NT>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;

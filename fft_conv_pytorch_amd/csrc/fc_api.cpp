@@ -651,8 +651,6 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.stamps = (unsigned long long*)p.debug_stamps;
-    a.delay_from = getenv("FFTCONV_DELAY_FROM") ? atoi(getenv("FFTCONV_DELAY_FROM")) : 256;
-    a.delay_ticks = getenv("FFTCONV_DELAY_TICKS") ? atoi(getenv("FFTCONV_DELAY_TICKS")) : 0;
     if (p.pers_nb) {
       fc::Conv1dPersArgs pa;
       pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;

@@ -170,13 +170,13 @@ constexpr int kPersNb0 = 0, kPersNb1 = 0;
 #endif
 constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_t)nb * 4 * GG::LSEQ) * sizeof(float2); }
 
-template <int NB, int DEPTH>
+template <int NB>
 hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   if constexpr (NB == 0) {
     return hipErrorInvalidValue;
   } else {
     constexpr int NT = NB * 4 * GG::TS;
-    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, DEPTH>;
+    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT>;
     const size_t lds = pers_lds_bytes(NB);
     static bool done = false;
     hipError_t e = ensure_lds(k, lds, &done);
@@ -187,9 +187,8 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
 }
 
 hipError_t pers_dispatch(int nb, const Conv1dPersArgs& a, int grid, hipStream_t st) {
-  static const int depth = getenv("FFTCONV_MIXDEPTH") ? atoi(getenv("FFTCONV_MIXDEPTH")) : 4;   // tuning knob
-  if (nb != 0 && nb == kPersNb0) return depth == 2 ? launch_pers<kPersNb0, 2>(a, grid, st) : launch_pers<kPersNb0, 4>(a, grid, st);
-  if (nb != 0 && nb == kPersNb1) return depth == 2 ? launch_pers<kPersNb1, 2>(a, grid, st) : launch_pers<kPersNb1, 4>(a, grid, st);
+  if (nb != 0 && nb == kPersNb0) return launch_pers<kPersNb0>(a, grid, st);
+  if (nb != 0 && nb == kPersNb1) return launch_pers<kPersNb1>(a, grid, st);
   return hipErrorInvalidValue;
 }
 

@@ -117,38 +117,44 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
       for (int k = 0; k < P; ++k) dst[P * k] = v[k];
     }
+    // ------------------------------------------------ mix
+    // The first two spectrum sets (and the self-paired bins' weights) do not depend on this item's
+    // transforms: they are requested BEFORE the barrier and travel while the slower waves finish.
+    const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
+    const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
+    // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
+    // lane (batch b, output o, bin) of wave 0 owns one real output.
+    const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
+    const bool sb_act = tid < NB * CIB * 2 && sb_b < wi.nbc;
+    f4 sbw[NPI];
+    if (sb_act) {
+#pragma unroll
+      for (int p = 0; p < NPI; ++p) sbw[p] = buf_load_f32x4(wg, (unsigned)sb_o * ostride, wbase + p * (T / 2) * 16);
+    }
+    // spectrum pipeline: step = (bin pair m, output pair q); two named register sets (static
+    // indices), both in flight: set A holds step s, set B step s+1, each is refilled with step s+2
+    // right after it has been contracted
+    auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
+      const unsigned vo = (unsigned)(tid + m * NT) * 16u;
+      const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#pragma unroll
+      for (int p = 0; p < NPI; ++p) {
+        dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
+        dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
+      }
+    };
+    f4 wA[2 * NPI], wB[2 * NPI];
+    issue(0, 0, wA);
+    issue(0, 1, wB);
     stamp_item(a.stamps, it, 4);
     __syncthreads();
     stamp_item(a.stamps, it, 5);
-    // ------------------------------------------------ mix
     {
-      const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
-      const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
-      // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
-      // lane (batch b, output o, bin) of wave 0 owns one real output.  Its loads are issued here and
-      // consumed after the main loop, so their latency is hidden (a one-lane serial loop cost ~8 us).
-      const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
-      const bool sb_act = tid < NB * CIB * 2 && sb_b < wi.nbc;
-      f4 sbw[NPI];
       f2 sbz[NPI];
       if (sb_act) {
 #pragma unroll
-        for (int p = 0; p < NPI; ++p) {
-          sbw[p] = buf_load_f32x4(wg, (unsigned)sb_o * ostride, wbase + p * (T / 2) * 16);
-          sbz[p] = zbuf[(sb_b * NPI + p) * G::LSEQ + G::nat(sb_f)];
-        }
+        for (int p = 0; p < NPI; ++p) sbz[p] = zbuf[(sb_b * NPI + p) * G::LSEQ + G::nat(sb_f)];
       }
-      // spectrum pipeline: step = (bin pair m, output pair q); two named register sets (static
-      // indices): the 2*NPI float4 of the next step are in flight while this one is contracted
-      auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
-        const unsigned vo = (unsigned)(tid + m * NT) * 16u;
-        const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-#pragma unroll
-        for (int p = 0; p < NPI; ++p) {
-          dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
-          dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
-        }
-      };
       f2 xe[NB][NPI], xo[NB][NPI];       // 2*X of the even / odd channel of every pair
       auto contract = [&](int f, int fm, int q, const f4 (&wc)[2 * NPI]) {
 #pragma unroll
@@ -167,8 +173,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           }
         }
       };
-      f4 wA[2 * NPI], wB[2 * NPI];
-      issue(0, 0, wA);
 #pragma unroll 1
       for (int m = 0; m < BP; ++m) {
         const int f = tid + m * NT;
@@ -198,11 +202,12 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         }
 #pragma unroll
         for (int q = 0; q < NPI; q += 2) {
-          issue(m, q + 1, wB);
           contract(f, fm, q, wA);
           if (q + 2 < NPI) issue(m, q + 2, wA);
           else if (m + 1 < BP) issue(m + 1, 0, wA);
           contract(f, fm, q + 1, wB);
+          if (q + 3 < NPI) issue(m, q + 3, wB);
+          else if (m + 1 < BP) issue(m + 1, 1, wB);
         }
       }
       if (sb_act) {

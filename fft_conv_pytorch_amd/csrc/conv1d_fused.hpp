@@ -37,6 +37,7 @@ struct Conv1dArgs {
   int n_ochunks;         // Cog_pad / cob
   int L, pad, pad_mode;  // source row length, left padding (may be negative for a transposed plan)
   int up;                // transposed plan: the source is spread over a grid of this step (zeros between)
+  int ph;                // batch-sharing kernel: dilation run as `ph` interleaved phases (virtual batch B*ph), else 1
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)

@@ -32,7 +32,7 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT>
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   constexpr int TWN = P * G::N2;            // pass-A twiddle table entries
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const Conv1dArgs& a = pa.c;
+  const int nph = PHASES ? a.ph : 1;          // dilation phases (compile-time 1 in the plain build)
 
   const int tid = threadIdx.x;
   const int sq = tid / G::TS;               // sequence slot: batch slot nb, channel pair p
@@ -62,28 +63,42 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 
   // ---- input samples of one item -> registers (unrolled buffer loads; border tiles get per-sample
   // padded / out-of-range offsets).  Only requests: nothing waits here.
+  // Dilation d (stride 1) runs as d interleaved phases: y[t*d + p] = sum_k w[k] x[(t + k)*d + p] is an
+  // undilated convolution of the phase-p samples, and all phases use the same spectrum -- so they ride
+  // the batch-sharing axis as a virtual batch of B*d items (slot vb -> batch vb / d, phase vb % d).
   auto fetch = [&](const WorkItem& wi, f2 (&v)[P]) {
     const int g = wi.goc / a.n_ochunks;
-    const int tile_pos = wi.tile * a.V - a.pad;
-    const bool interior = (tile_pos >= 0) && (tile_pos + T <= a.L);
+    const int vb = wi.b0 + nb;
+    const int bfirst = wi.b0 / nph, blast = (wi.b0 + wi.nbc - 1) / nph;
+    const int b = vb / nph, phase = vb - b * nph;
+    const int pos0 = wi.tile * a.V * nph + phase - a.pad;          // source position of the tile's first sample
+    const bool interior = (pos0 >= 0) && (pos0 + (T - 1) * nph < a.L);
     const bool act_in = nb < wi.nbc;
-    const float* xbase = a.x + ((size_t)wi.b0 * a.Cin + (size_t)g * a.Cig) * a.L;
-    const BufRsrc xg = make_rsrc(xbase, (unsigned)(((size_t)(wi.nbc - 1) * a.Cin + a.Cig) * a.L * 4));
+    const float* xbase = a.x + ((size_t)bfirst * a.Cin + (size_t)g * a.Cig) * a.L;
+    const BufRsrc xg = make_rsrc(xbase, (unsigned)(((size_t)(blast - bfirst) * a.Cin + a.Cig) * a.L * 4));
     const int ci0 = 2 * pr;
     const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
-    const unsigned ro0 = ((unsigned)nb * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
+    const unsigned ro0 = ((unsigned)(b - bfirst) * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
     const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
-    if (interior && has1) {
-      const unsigned v0 = ro0 + (unsigned)(tile_pos + tseq) * 4u, v1 = ro1 + (unsigned)(tile_pos + tseq) * 4u;
+    if (interior && has1 && !PHASES) {
+      const unsigned v0 = ro0 + (unsigned)(pos0 + tseq) * 4u, v1 = ro1 + (unsigned)(pos0 + tseq) * 4u;
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
         v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
         v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
       }
+    } else if (interior && has1) {
+      const unsigned v0 = ro0 + (unsigned)(pos0 + tseq * nph) * 4u, v1 = ro1 + (unsigned)(pos0 + tseq * nph) * 4u;
+      const unsigned step = (unsigned)(G::N2 * 4) * (unsigned)nph;
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        v[n1].x = buf_load_f32(xg, v0, step * n1);
+        v[n1].y = buf_load_f32(xg, v1, step * n1);
+      }
     } else {
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
-        const int pos = tile_pos + G::N2 * n1 + tseq;
+        const int pos = pos0 + (G::N2 * n1 + tseq) * nph;
         v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
         v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
       }
@@ -238,14 +253,23 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       passB_load<G>(v, zseq, tseq);
       const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;
-      const int t0 = wi.tile * a.V;
-      const int limit = min(a.V, a.Lfull - t0);
+      const int vb = wi.b0 + nb;
+      const int b = vb / nph, phase = vb - b * nph;
+      const int t0 = wi.tile * a.V;                                   // in samples of this phase
+      const int limit = min(a.V, (a.Lfull - phase + nph - 1) / nph - t0);
       const int nbase = o1 + P * P * j;
-      float* y0 = a.y + ((size_t)(wi.b0 + nb) * a.Cout + cg0) * a.Lout + t0 + nbase;
+      float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase) * nph + phase;
       float* y1 = y0 + a.Lout;
+      if (!PHASES) {
 #pragma unroll
-      for (int k = 0; k < P; ++k)
-        if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
+      } else {
+        const int ystep = P * nph;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) { y0[ystep * k] = v[k].x + bias0; y1[ystep * k] = v[k].y + bias1; }
+      }
     }
     stamp_item(a.stamps, it, 10);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }

@@ -123,6 +123,7 @@ struct fc_plan {
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
   int pers_nb_choice;         // planner's pick for this plan (0 = general kernel)
   int pers_grid, pers_items;
+  int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
 };
 
@@ -134,6 +135,7 @@ const char* fc_last_error(void) { return g_err.c_str(); }
 
 static int plan_1d_persistent(fc_plan* p);
 static int choose_fast_path(fc_plan* p, int* tile_out);
+static bool fast_path_eligible(const fc_plan* p);
 
 static int plan_1d(fc_plan* p) {
   const fc_desc& d = p->d;
@@ -151,19 +153,25 @@ static int plan_1d(fc_plan* p) {
   auto tiles = all_tiles(&ntl);
   int forced_tile = d.tile_hint;
   p->pers_nb_choice = 0;
+  p->ph = 1;
   if (!forced_tile) {
     int rc = choose_fast_path(p, &forced_tile);
     if (rc != FC_OK) return rc;
+  } else if (d.dilation[0] > 1 && fast_path_eligible(p) && getenv("FFTCONV_PERS") && atoi(getenv("FFTCONV_PERS")) > 0) {
+    p->ph = (int)d.dilation[0];           // explicit tile + explicit flavour: dilation as phases
   }
+  // dilation as phases: the kernel seen by a tile is the undilated one, rows are 1/ph as long
+  const int64_t Kd_t = p->ph > 1 ? d.kernel[0] : Kd;
+  const int64_t Lfull_t = p->ph > 1 ? (Lfull + p->ph - 1) / p->ph : Lfull;
   for (int i = 0; i < ntl; ++i) {
     const fc::TileImpl* t = tiles[i];
     if (forced_tile && t->T != forced_tile) continue;
-    if (t->T < Kd) continue;
+    if (t->T < Kd_t) continue;
     const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
     if (lds > lds_cap) continue;
     if (t->NT / (t->P * t->S) < NPI) continue;
-    const int64_t V = t->T - Kd + 1;
-    const int64_t nt = (Lfull + V - 1) / V;
+    const int64_t V = t->T - Kd_t + 1;
+    const int64_t nt = (Lfull_t + V - 1) / V;
     // work model: FFT passes + channel mix per tile; the largest tile runs one
     // workgroup per CU (LDS), which costs latency hiding
     double cost = (double)nt * t->T * (2.0 * std::log2((double)t->T) + 4.0 + p->CB);
@@ -177,8 +185,8 @@ static int plan_1d(fc_plan* p) {
     return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld exceeds the largest FFT tile (4096)", (long long)Kd);
   }
   p->tile = best;
-  p->V = (int)(best->T - Kd + 1);
-  p->ntiles = (int)((Lfull + p->V - 1) / p->V);
+  p->V = (int)(best->T - Kd_t + 1);
+  p->ntiles = (int)((Lfull_t + p->V - 1) / p->V);
   p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * NPI * best->lseq * sizeof(fc::f2);
   p->lds_spec = (size_t)(best->NT / (best->P * best->S)) * best->lseq * sizeof(fc::f2);
   const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(fc::f4);
@@ -188,7 +196,10 @@ static int plan_1d(fc_plan* p) {
   p->workspace_bytes = 0;
   int rc = get_twiddles(best, &p->tw);
   if (rc != FC_OK) return rc;
-  return plan_1d_persistent(p);
+  rc = plan_1d_persistent(p);
+  if (rc == FC_OK && p->ph > 1 && p->pers_nb == 0)
+    return fail(FC_ERR_INVALID, "internal: phase plan without the batch-sharing kernel");
+  return rc;
 }
 
 
@@ -212,29 +223,38 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int64_t Kd = p->kd[0], Lfull = p->Lf[0], B = d.batch;
   const int64_t per_item_units = (int64_t)p->n_ochunks * d.groups;
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
   const Cand cands[] = {{256, 0, 8, 10.9}, {512, 0, 6, 10.4}, {1024, 0, 4, 24.0}, {2048, 0, 2, 26.4},
                         {2048, 2, 1, 19.5}, {1024, 2, 2, 16.0}, {1024, 4, 1, 15.0}};
   double best = 0;
-  int best_T = 0, best_nb = 0;
-  for (const Cand& c : cands) {
-    if (c.T < Kd || p->accumulate) continue;
-    if (c.nb != 0 && (!fast_ok || c.nb > B)) continue;
-    if (want > 0 && c.nb != want) continue;
-    const int64_t V = c.T - Kd + 1;
-    if (V * 4 < c.T) continue;                      // less than a quarter of the tile useful: leave to the cost model
-    const int64_t nt = (Lfull + V - 1) / V;
-    const int64_t items = ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt * per_item_units;
-    const int64_t slots = (int64_t)cus * c.wgs_per_cu;
-    const double est = (double)((items + slots - 1) / slots) * c.t_item;
-    if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; }
+  int best_T = 0, best_nb = 0, best_ph = 1;
+  // second round: dilation d as d phases of a virtual batch B*d against the undilated kernel
+  const int rounds = (fast_ok && d.dilation[0] > 1) ? 2 : 1;
+  for (int round = 0; round < rounds; ++round) {
+    const int ph = round ? (int)d.dilation[0] : 1;
+    const int64_t Kd = round ? d.kernel[0] : p->kd[0];
+    const int64_t Lfull = (p->Lf[0] + ph - 1) / ph;
+    const int64_t B = d.batch * ph;
+    for (const Cand& c : cands) {
+      if (round && c.nb == 0) continue;               // only the batch-sharing kernel knows phases
+      if (c.T < Kd || p->accumulate) continue;
+      if (c.nb != 0 && (!fast_ok || c.nb > B)) continue;
+      if (want > 0 && c.nb != want) continue;
+      const int64_t V = c.T - Kd + 1;
+      if (V * 4 < c.T) continue;                      // less than a quarter of the tile useful: leave to the cost model
+      const int64_t nt = (Lfull + V - 1) / V;
+      const int64_t items = ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt * per_item_units;
+      const int64_t slots = (int64_t)cus * c.wgs_per_cu;
+      const double est = (double)((items + slots - 1) / slots) * c.t_item;
+      if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; best_ph = ph; }
+    }
   }
   if (best_T == 0) return FC_OK;                    // general planner (cost model) decides
   *tile_out = best_T;
   p->pers_nb_choice = best_nb;
+  p->ph = best_ph;
   return FC_OK;
 }
 
@@ -248,7 +268,7 @@ static int plan_1d_persistent(fc_plan* p) {
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int64_t B = d.batch;
+  const int64_t B = d.batch * p->ph;                 // virtual batch (dilation phases)
   int nb = p->pers_nb_choice;
   if (d.tile_hint) {                                // explicit tile: FFTCONV_PERS picks the flavour (default general)
     const char* env = getenv("FFTCONV_PERS");
@@ -270,8 +290,8 @@ static int plan_1d_persistent(fc_plan* p) {
     const int T = t->T, V = p->V;
     for (int pass = 0; pass < 2; ++pass)
       for (int tile = 0; tile < p->ntiles; ++tile) {
-        const int64_t pos = (int64_t)tile * V - p->padl[0];
-        const bool interior = p->up[0] == 1 && pos >= 0 && pos + T <= d.spatial[0];
+        const int64_t pos = (int64_t)tile * V * p->ph - p->padl[0];
+        const bool interior = p->up[0] == 1 && pos >= 0 && pos + (int64_t)(T - 1) * p->ph + p->ph <= d.spatial[0];
         if ((pass == 0) == !interior) tile_order.push_back(tile);
       }
   }
@@ -583,7 +603,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.twA = p.tw.twA;
     a.twB = p.tw.twB;
     a.G = (int)p.d.groups; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
-    a.K = (int)p.d.kernel[0]; a.dil = (int)p.d.dilation[0];
+    a.K = (int)p.d.kernel[0]; a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
     a.transposed = p.d.transposed;
     const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
@@ -647,7 +667,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.twA = p.tw.twA; a.twB = p.tw.twB;
     a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
-    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0];
+    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.stamps = (unsigned long long*)p.debug_stamps;

@@ -176,8 +176,16 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
     return hipErrorInvalidValue;
   } else {
     constexpr int NT = NB * 4 * GG::TS;
-    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT>;
     const size_t lds = pers_lds_bytes(NB);
+    if (a.c.ph > 1) {            // dilation as phases: separate build so the plain kernel keeps its immediates
+      auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, true>;
+      static bool done = false;
+      hipError_t e = ensure_lds(k, lds, &done);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+      return hipGetLastError();
+    }
+    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, false>;
     static bool done = false;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;

@@ -123,6 +123,7 @@ struct fc_plan {
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
   int pers_nb_choice;         // planner's pick for this plan (0 = general kernel)
   int pers_grid, pers_items;
+  int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
 };
@@ -154,7 +155,26 @@ static int plan_1d(fc_plan* p) {
   int forced_tile = d.tile_hint;
   p->pers_nb_choice = 0;
   p->ph = 1;
-  if (!forced_tile) {
+  p->wide = 0;
+  {
+    // more than 8 input channels per group, whole out-chunks, stride 1: the register-accumulating
+    // batch-sharing kernel (1024 or 2048 tile, whichever keeps at least a quarter of the tile valid).
+    // Short kernels stay with the general kernel and its small tiles (measured: 16->16, k = 33, L = 4096:
+    // 24.6 us there vs 29.1 us here; k = 129 ... 1025: 2.0-2.5x faster here).
+    const char* env = getenv("FFTCONV_WIDE");
+    const int want_wide = env ? atoi(env) : 1;
+    if (want_wide && p->CB == 8 && p->accumulate && p->Cog % 8 == 0 && d.stride[0] == 1 && d.batch >= 2 &&
+        ((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 < ((int64_t)1 << 32)) {
+      const int wt = Kd < 97 ? 0 : (Kd <= 768 ? 1024 : (Kd <= 1536 ? 2048 : 0));
+      if (wt && (!forced_tile || forced_tile == wt) && find_tile(wt) && find_tile(wt)->wide_nb) {
+        p->wide = 1;
+        forced_tile = wt;
+      }
+    }
+  }
+  if (p->wide) {
+    // tile fixed above
+  } else if (!forced_tile) {
     int rc = choose_fast_path(p, &forced_tile);
     if (rc != FC_OK) return rc;
   } else if (d.dilation[0] > 1 && fast_path_eligible(p) && getenv("FFTCONV_PERS") && atoi(getenv("FFTCONV_PERS")) > 0) {
@@ -167,7 +187,7 @@ static int plan_1d(fc_plan* p) {
     const fc::TileImpl* t = tiles[i];
     if (forced_tile && t->T != forced_tile) continue;
     if (t->T < Kd_t) continue;
-    const size_t lds = (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
+    const size_t lds = p->wide ? t->wide_lds : (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
     if (lds > lds_cap) continue;
     if (t->NT / (t->P * t->S) < NPI) continue;
     const int64_t V = t->T - Kd_t + 1;
@@ -263,21 +283,27 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
 static int plan_1d_persistent(fc_plan* p) {
   p->pers_nb = 0; p->d_items = nullptr; p->pers_items = 0; p->pers_grid = 0;
   const fc_desc& d = p->d;
-  if (!fast_path_eligible(p)) return FC_OK;
+  if (!p->wide && !fast_path_eligible(p)) return FC_OK;
   const fc::TileImpl* t = p->tile;
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   const int64_t B = d.batch * p->ph;                 // virtual batch (dilation phases)
   int nb = p->pers_nb_choice;
-  if (d.tile_hint) {                                // explicit tile: FFTCONV_PERS picks the flavour (default general)
+  if (d.tile_hint && !p->wide) {                    // explicit tile: FFTCONV_PERS picks the flavour (default general)
     const char* env = getenv("FFTCONV_PERS");
     nb = env ? atoi(env) : 0;
   }
-  if (nb != t->pers_nb[0] && nb != t->pers_nb[1]) nb = 0;
-  if (nb == 0) return FC_OK;
-  int slot = nb == t->pers_nb[0] ? 0 : 1;
-  const int wgs_per_cu = std::max(1, (int)((160 * 1024) / t->pers_lds[slot]));
+  int wgs_per_cu;
+  if (p->wide) {
+    nb = t->wide_nb;
+    wgs_per_cu = std::max(1, (int)((160 * 1024) / t->wide_lds));
+  } else {
+    if (nb != t->pers_nb[0] && nb != t->pers_nb[1]) nb = 0;
+    if (nb == 0) return FC_OK;
+    const int slot = nb == t->pers_nb[0] ? 0 : 1;
+    wgs_per_cu = std::max(1, (int)((160 * 1024) / t->pers_lds[slot]));
+  }
   // Items: up to nb batch items that share (tile, group, out-chunk), full items first.  When the last
   // residency round would fill less than half of the CUs, its items are split in two so the tail
   // spreads over twice as many CUs (cfgA: 336 pairs on 256 CUs -> 256 pairs + 160 singles).
@@ -319,6 +345,7 @@ static int plan_1d_persistent(fc_plan* p) {
   p->pers_items = (int)items.size();
   // up to two items per workgroup (the second one's input is prefetched): item i and i + grid
   p->pers_grid = (int)std::max<int64_t>((p->pers_items + 1) / 2, std::min<int64_t>(p->pers_items, slots));
+  if (p->wide) p->pers_grid = p->pers_items;         // one item per workgroup
   FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
   FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;
@@ -674,7 +701,8 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     if (p.pers_nb) {
       fc::Conv1dPersArgs pa;
       pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;
-      FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
+      if (p.wide) FC_HIP(p.tile->conv1d_wide(pa, p.pers_grid, st));
+      else FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
       return FC_OK;
     }
     const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "conv1d_fused.hpp"
 #include "conv1d_pers.hpp"
+#include "conv1d_wide.hpp"
 #include "nd_passes.hpp"
 #include "spectrum1d.hpp"
 #include "wgrad1d.hpp"
@@ -28,6 +29,10 @@ struct TileImpl {
   int pers_nb[2];        // supported nb values (0 = none)
   size_t pers_lds[2];    // LDS bytes for each
   int pers_nt[2];
+  // batch-sharing kernel for > 8 input channels per group (conv1d_wide.hpp); wide_nb = 0 when not built
+  hipError_t (*conv1d_wide)(const Conv1dPersArgs& a, int grid, hipStream_t st);
+  int wide_nb;
+  size_t wide_lds;
   // 1-D weight gradient (wgrad1d.hpp), built for the 1024-point tile only (else null)
   hipError_t (*wgrad1d)(const WGradArgs& a, int grid, hipStream_t st);
   int wgrad_nb;          // items per iteration of that kernel

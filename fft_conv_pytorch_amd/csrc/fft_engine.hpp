@@ -289,6 +289,31 @@ __device__ __forceinline__ void passA_fft_twiddle_store_lds(f2 (&v)[G::P], f2* _
   for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
 }
 
+// same, with the table read in two halves (half the twiddle registers live at a time): for kernels that
+// carry many accumulators across the transform
+template <class G, int DIR>
+__device__ __forceinline__ void passA_fft_twiddle_store_lds_lowreg(f2 (&v)[G::P], f2* __restrict__ lseq, int n2,
+                                                                   const f2* __restrict__ twl) {
+  fft_regs<G::P, DIR>(v);
+  lseq[n2] = v[0];
+  constexpr int H = G::P / 2;
+  const unsigned addr = lds_off(twl + n2);
+  static_for<0, 2>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    f2 w[H];
+    static_for<0, H>([&](auto ic) {
+      constexpr int k1 = h * H + decltype(ic)::value;
+      w[decltype(ic)::value] = lds_rd<k1 * G::N2 * 8>(addr);
+    });
+    lds_arrive(w);
+#pragma unroll
+    for (int i = (h == 0 ? 1 : 0); i < H; ++i) {
+      const int k1 = h * H + i;
+      lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[i]) : cmul(v[k1], w[i]);
+    }
+  });
+}
+
 // Pass-B load: lane (k1, r) of the sequence reads a[S*m + r] of row k1.
 template <class G>
 __device__ __forceinline__ void passB_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {

@@ -200,6 +200,23 @@ hipError_t pers_dispatch(int nb, const Conv1dPersArgs& a, int grid, hipStream_t 
   return hipErrorInvalidValue;
 }
 
+#if FC_P == 32 && (FC_S == 1 || FC_S == 2)
+constexpr int kWideNb = 2;
+hipError_t wide_dispatch(const Conv1dPersArgs& a, int grid, hipStream_t st) {
+  constexpr int NT = kWideNb * 4 * GG::TS;
+  auto k = conv1d_wide_kernel<FC_P, FC_S, kWideNb, NT>;
+  const size_t lds = pers_lds_bytes(kWideNb);
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+#else
+constexpr int kWideNb = 0;
+hipError_t wide_dispatch(const Conv1dPersArgs&, int, hipStream_t) { return hipErrorInvalidValue; }
+#endif
+
 #if FC_P == 32 && FC_S == 1
 constexpr int kWgradNb = 2;
 hipError_t wgrad_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
@@ -227,6 +244,7 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
                                 pers_dispatch, {kPersNb0, kPersNb1},
                                 {kPersNb0 ? pers_lds_bytes(kPersNb0) : 0, kPersNb1 ? pers_lds_bytes(kPersNb1) : 0},
                                 {kPersNb0 * 4 * GG::TS, kPersNb1 * 4 * GG::TS},
+                                wide_dispatch, kWideNb, kWideNb ? pers_lds_bytes(kWideNb) : 0,
 #if FC_P == 32 && FC_S == 1
                                 wgrad_dispatch,
 #else

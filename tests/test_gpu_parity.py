@@ -327,3 +327,32 @@ def test_weight_gradient_kernel(case):
     err = (got.double().cpu() - want).norm().item() / want.norm().item()
     print(f"wgrad {case}: rel err {err:.2e}")
     assert err < REL_TOL
+
+
+WIDE_CASES = [  # B, Cin, Cout, groups, L, K, padding, mode  (more than 8 input channels per group, k >= 97)
+    (8, 64, 64, 1, 16384, 129, 0, "constant"),
+    (3, 16, 8, 1, 5000, 100, 16, "reflect"),
+    (5, 24, 16, 1, 3000, 200, 7, "circular"),
+    (2, 20, 8, 1, 2500, 700, 0, "constant"),          # 20 channels: the last chunk is half empty
+    (4, 32, 32, 2, 9000, 1025, 100, "replicate"),     # 2048 tile
+    (7, 9, 8, 1, 1200, 97, 2, "constant"),            # odd batch: a one-item remainder
+]
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_wide_input_kernel(case):
+    """conv1d_wide_kernel (running sums of the out-chunk in registers over the input chunks) against torch's
+    direct convolution in float64, and against the general kernel it replaces (FFTCONV_WIDE=0 plans)."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    B, cin, cout, groups, L, K, pad, mode = case
+    gen = torch.Generator().manual_seed(4321 + L)
+    x = torch.randn(B, cin, L, generator=gen)
+    w = torch.randn(cout, cin // groups, K, generator=gen) / (K * cin) ** 0.5
+    b = torch.randn(cout, generator=gen)
+    xp = F.pad(x.double(), [pad, pad], mode=mode) if (mode != "constant" and pad) else x.double()
+    want = F.conv1d(xp, w.double(), b.double(), padding=pad if mode == "constant" else 0, groups=groups)
+    got = fft_conv(x.to(DEV), w.to(DEV), b.to(DEV), padding=pad, padding_mode=mode, groups=groups)
+    assert got.shape == want.shape
+    err = (got.double().cpu() - want).norm().item() / want.norm().item()
+    print(f"wide {case}: rel err {err:.2e}")
+    assert err < REL_TOL

@@ -5,7 +5,7 @@ The reference has no custom backward: autograd differentiates its rfftn/einsum/i
 autograd, so the three gradients are expressed as convolutions the native library already runs:
 
     dX = conv_transpose(dY, W)             -> ``fc_forward`` on a transposed plan
-    dW = correlate(X, dY) over the batch   -> 1-D, stride 1, <= 8 channels per group: ``fc_wgrad1d`` (cross-spectra
+    dW = correlate(X, dY) over the batch   -> 1-D, stride 1, <= 64 channels per group: ``fc_wgrad1d`` (cross-spectra
                                               accumulated on chip); otherwise ``fc_forward`` with the roles of
                                               batch and channels swapped: signal' = X^T (Cin/g, B, *S), kernel' =
                                               dY^T (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;

@@ -542,7 +542,7 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   if (d.ndim != 1 || d.dtype != FC_F32 || d.transposed || d.stride[0] != 1 || d.groups < 1) return 0;
   if (d.batch < 1 || d.in_channels % d.groups || d.out_channels % d.groups) return 0;
   const int64_t Cig = d.in_channels / d.groups, Cog = d.out_channels / d.groups;
-  if (Cig > 8 || Cog > 8) return 0;
+  if (Cig > 64 || Cog > 64) return 0;      // every 4 x 4 channel block repeats the transforms of its rows: beyond this the plan path wins
   const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
   const fc::TileImpl* t = find_tile(1024);
   if (!t || !t->wgrad1d || kd > 768 || d.padding[0] < 0) return 0;

@@ -304,6 +304,7 @@ WGRAD_CASES = [  # B, Cin, Cout, groups, L, K, padding, dilation, mode
     (7, 8, 8, 1, 3000, 385, 100, 2, "circular"),      # dilated extent 769 > 768: falls back to the plan path
     (4, 7, 8, 1, 1500, 200, 30, 1, "replicate"),
     (9, 8, 8, 8, 10000, 65, 5, 1, "constant"),        # depthwise-like: one channel per group
+    (2, 24, 40, 1, 3000, 65, 0, 1, "constant"),       # 6 x 10 blocks of 4 x 4 channels
 ]
 
 

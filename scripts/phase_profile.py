@@ -18,11 +18,13 @@ ap.add_argument("--ch", type=int, default=8)
 ap.add_argument("--len", type=int, default=32768)
 ap.add_argument("--k", type=int, default=512)
 ap.add_argument("--tile", type=int, default=0)
+ap.add_argument("--dil", type=int, default=1)
+ap.add_argument("--groups", type=int, default=1)
 args = ap.parse_args()
 if args.tile:
     os.environ["FFTCONV_TILE"] = str(args.tile)
 dev = "cuda:0"
-layer = fca.FFTConv1d(args.ch, args.ch, args.k).to(dev)
+layer = fca.FFTConv1d(args.ch, args.ch, args.k, dilation=args.dil, groups=args.groups).to(dev)
 x = torch.randn(args.batch, args.ch, args.len, device=dev)
 for _ in range(3):
     y = layer(x)

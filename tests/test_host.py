@@ -81,3 +81,15 @@ def test_product_package_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("no CPU", ""), fn
             assert "torch.fft" not in src.replace("no torch.fft", ""), fn
+
+
+def test_wgrad_descriptor_query_is_safe_without_a_device():
+    """fc_wgrad1d_slices is a pure query: it must answer (0 = not covered / no device) and never raise."""
+    from fft_conv_pytorch_amd import _native
+    ok = _native.conv_desc(1, 4, 8, 8, 1, (4096,), (33,), (1,), (0,), (1,), 0)
+    strided = _native.conv_desc(1, 4, 8, 8, 1, (4096,), (33,), (2,), (0,), (1,), 0)
+    two_d = _native.conv_desc(2, 4, 8, 8, 1, (64, 64), (3, 3), (1, 1), (0, 0), (1, 1), 0)
+    has_gpu = torch.cuda.is_available()
+    assert (_native.wgrad1d_slices(ok) > 0) == has_gpu
+    assert _native.wgrad1d_slices(strided) == 0
+    assert _native.wgrad1d_slices(two_d) == 0

@@ -246,7 +246,7 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   const int64_t per_item_units = (int64_t)p->n_ochunks * d.groups;
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
-  const Cand cands[] = {{256, 0, 8, 10.9}, {512, 0, 6, 10.4}, {1024, 0, 4, 24.0}, {2048, 0, 2, 26.4},
+  const Cand cands[] = {{256, 0, 8, 11.7}, {512, 0, 6, 17.0}, {1024, 0, 4, 25.5}, {2048, 0, 2, 28.9},
                         {2048, 2, 1, 19.5}, {1024, 2, 2, 16.0}, {1024, 4, 1, 15.0}};
   double best = 0;
   int best_T = 0, best_nb = 0, best_ph = 1;

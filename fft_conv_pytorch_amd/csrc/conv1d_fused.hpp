@@ -137,8 +137,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       const int ci0 = ic * CIB + 2 * sq;         // channel within the group
       f2 v[P];
       const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;
-      const float* r0 = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig + ci0) * a.L;
-      const float* r1 = r0 + a.L;
+      // rows of phantom channels (ci >= Cig in the last chunk) must not be dereferenced at all: the padded
+      // loaders read row[0] even for a masked lane, and past the last group that is past the tensor
+      const float* rgrp = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L;
+      const float* r0 = has0 ? rgrp + (size_t)ci0 * a.L : rgrp;
+      const float* r1 = has1 ? r0 + a.L : rgrp;
       if (interior && has1) {
         const unsigned v0 = ((unsigned)ci0 * (unsigned)a.L + (unsigned)(tile_pos + tseq)) * 4u;
         const unsigned v1 = v0 + (unsigned)a.L * 4u;
@@ -157,9 +160,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         for (int n1 = 0; n1 < P; ++n1) {
           const int pos = tile_pos + G::N2 * n1 + tseq;
           col[n1 * G::RS] = (a.up == 1)
-                                ? mk2(load_padded(r0, pos, a.L, a.pad, pm, has0),
-                                      load_padded(has1 ? r1 : r0, pos, a.L, a.pad, pm, has1))
-                                : mk2(load_spread(r0, pos, a.L, a.up, has0), load_spread(has1 ? r1 : r0, pos, a.L, a.up, has1));
+                                ? mk2(load_padded(r0, pos, a.L, a.pad, pm, has0), load_padded(r1, pos, a.L, a.pad, pm, has1))
+                                : mk2(load_spread(r0, pos, a.L, a.up, has0), load_spread(r1, pos, a.L, a.up, has1));
         }
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];

@@ -98,16 +98,22 @@ def transform_kernel(plan, kernel: Tensor) -> KernelSpectrum:
     return KernelSpectrum(plan, buf, ws)
 
 
-def _forward_native(signal: Tensor, spectrum: KernelSpectrum, bias: Optional[Tensor]) -> Tensor:
+def _launch_forward(signal: Tensor, spectrum: KernelSpectrum, bias_c: Optional[Tensor]) -> Tensor:
     plan = spectrum.plan
+    out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=torch.float32, device=signal.device)
+    stream = torch.cuda.current_stream(signal.device).cuda_stream
+    plan.forward(signal.data_ptr(), spectrum.buf.data_ptr(), bias_c.data_ptr() if bias_c is not None else None,
+                 out.data_ptr(), spectrum.workspace.data_ptr() if spectrum.workspace is not None else None, stream)
+    return out
+
+
+def _forward_native(signal: Tensor, spectrum: KernelSpectrum, bias: Optional[Tensor]) -> Tensor:
     signal = signal.detach().contiguous()
     bias_c = bias.detach().contiguous() if bias is not None else None
+    if torch.cuda.current_device() == signal.device.index:      # the common case: no device switch to pay for
+        return _launch_forward(signal, spectrum, bias_c)
     with torch.cuda.device(signal.device):
-        out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=torch.float32, device=signal.device)
-        stream = torch.cuda.current_stream(signal.device).cuda_stream
-        plan.forward(signal.data_ptr(), spectrum.buf.data_ptr(), bias_c.data_ptr() if bias_c is not None else None,
-                     out.data_ptr(), spectrum.workspace.data_ptr() if spectrum.workspace is not None else None, stream)
-    return out
+        return _launch_forward(signal, spectrum, bias_c)
 
 
 def fft_conv(
@@ -138,14 +144,16 @@ def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, spectrum):
-    """Shared by the functional and the modules; ``spectrum`` is an optional cached kernel transform."""
+def _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, spectrum, plan=None):
+    """Shared by the functional and the modules; ``spectrum`` is an optional cached kernel transform and
+    ``plan`` the plan the caller already looked up (and validated) for exactly these arguments."""
     if _needs_grad(signal, kernel, bias):
         from .autograd import FFTConvFunction        # backward built from the same kernels (row N1)
         n = signal.ndim - 2
         return FFTConvFunction.apply(signal, kernel, bias, to_ntuple(stride, n), to_ntuple(padding, n),
                                      to_ntuple(dilation, n), groups, padding_mode, spectrum)
-    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode)
+    if plan is None:
+        plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, padding_mode)
     if spectrum is None or spectrum.plan is not plan:
         spectrum = transform_kernel(plan, kernel)   # the reference also re-transforms per call (functional.py:71)
     return _forward_native(signal, spectrum, bias)

@@ -202,6 +202,9 @@ static int plan_1d(fc_plan* p) {
   }
   if (!best) {
     if (d.tile_hint) return fail(FC_ERR_INVALID, "tile_hint %d is not usable for this problem", d.tile_hint);
+    if (Kd <= 4096)
+      return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld needs the 4096-point tile, which cannot hold the running "
+                  "sums of more than 8 input channels per group (%d here)", (long long)Kd, p->Cig);
     return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld exceeds the largest FFT tile (4096)", (long long)Kd);
   }
   p->tile = best;

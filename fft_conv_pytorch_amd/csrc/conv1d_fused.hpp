@@ -39,7 +39,9 @@ struct Conv1dArgs {
   int up;                // transposed plan: the source is spread over a grid of this step (zeros between)
   int ph;                // batch-sharing kernel: dilation run as `ph` interleaved phases (virtual batch B*ph), else 1
   int Kd, V, ntiles, Lfull, Lout, stride;
-  int accumulate;        // 1 when Cig_pad > CIB (separate output region in LDS)
+  int accumulate;        // 1 when this launch covers several input chunks (separate output region in LDS)
+  int ic_begin, ic_end;  // input chunks of this launch (all of them unless the plan launches chunk by chunk)
+  int add_out;           // 1: y += result (later chunk launches of such a plan; bias went with the first)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
 };
 
@@ -118,7 +120,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   f2* zin = lds;
   f2* vout = a.accumulate ? lds + NPI * G::LSEQ : lds;
 
-  const int n_ichunks = a.Cig_pad / CIB;
   const int tile_pos = tile * a.V - a.pad;     // signal coordinate of tile sample 0
   const bool interior = a.up == 1 && (tile_pos >= 0) && (tile_pos + T <= a.L);
   const PadMap pm = make_padmap(a.pad_mode, a.L);
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
 
   stamp(a.stamps, 0);
-  for (int ic = 0; ic < n_ichunks; ++ic) {
+  for (int ic = a.ic_begin; ic < a.ic_end; ++ic) {
     // ------------------------------------------------ forward pass A (global -> regs -> LDS)
     if (seq0 < NPI) {
       const int sq = seq0;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           f2 vg = conj_add_iconj(ya, yb);
           f2* pf = vout + q * G::LSEQ + G::nat(fc);
           f2* pg = vout + q * G::LSEQ + G::nat(fm);
-          if (ic != 0) { vf += *pf; vg += *pg; }
+          if (ic != a.ic_begin) { vf += *pf; vg += *pg; }
           *pf = vf; *pg = vg;
         }
       };
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
           acc = fmaf(2.f * sbz[p].y, (tid & 1) ? sbw[p].w : sbw[p].z, acc);
         }
         float* dstf = reinterpret_cast<float*>(vout + (sb_o >> 1) * G::LSEQ + G::nat(sb_f)) + (sb_o & 1);
-        if (ic != 0) acc += *dstf;
+        if (ic != a.ic_begin) acc += *dstf;
         *dstf = acc;
       }
     }
@@ -319,7 +320,21 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
     const int t0 = tile * a.V;
     const int limit = min(a.V, a.Lfull - t0);      // valid samples of this tile
     const int nbase = o1 + P * P * j;
-    if (a.stride == 1) {
+    if (a.add_out) {
+      // chunk-by-chunk plan, chunks after the first: accumulate into the output already in HBM
+      float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout;
+      float* y1 = y0 + a.Lout;
+#pragma unroll
+      for (int k = 0; k < P; ++k) {
+        const int n = nbase + P * k;
+        const int t = t0 + n;
+        const int idx = t / a.stride;
+        if (n < limit && idx * a.stride == t) {
+          if (has0) y0[idx] += v[k].x;
+          if (has1) y1[idx] += v[k].y;
+        }
+      }
+    } else if (a.stride == 1) {
       float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + t0 + nbase;
       float* y1 = y0 + a.Lout;
       if (has1) {

@@ -123,6 +123,7 @@ struct fc_plan {
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
   int pers_nb_choice;         // planner's pick for this plan (0 = general kernel)
   int pers_grid, pers_items;
+  int chunk_launches;         // general kernel launched once per input chunk, later chunks add into y (see plan_1d)
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
@@ -183,6 +184,15 @@ static int plan_1d(fc_plan* p) {
   // dilation as phases: the kernel seen by a tile is the undilated one, rows are 1/ph as long
   const int64_t Kd_t = p->ph > 1 ? d.kernel[0] : Kd;
   const int64_t Lfull_t = p->ph > 1 ? (Lfull + p->ph - 1) / p->ph : Lfull;
+  p->chunk_launches = 0;
+  for (int attempt = 0; attempt < 2 && !best; ++attempt) {
+  if (attempt == 1) {
+    // No tile holds the kernel together with the second (running-sum) LDS region of a multi-chunk plan:
+    // launch the general kernel once per input chunk instead, chunks after the first adding into y.
+    if (!p->accumulate || p->wide || forced_tile) break;
+    p->accumulate = 0;
+    p->chunk_launches = 1;
+  }
   for (int i = 0; i < ntl; ++i) {
     const fc::TileImpl* t = tiles[i];
     if (forced_tile && t->T != forced_tile) continue;
@@ -199,6 +209,7 @@ static int plan_1d(fc_plan* p) {
     // 4096 tile ~1.7x per sample of tile; it only wins when the kernel is nearly as long as 2048
     if (lds > 80 * 1024) cost *= 1.7;
     if (!best || cost < best_cost) { best = t; best_cost = cost; }
+  }
   }
   if (!best) {
     if (d.tile_hint) return fail(FC_ERR_INVALID, "tile_hint %d is not usable for this problem", d.tile_hint);
@@ -228,7 +239,7 @@ static int plan_1d(fc_plan* p) {
 
 static bool fast_path_eligible(const fc_plan* p) {
   const fc_desc& d = p->d;
-  if (p->CB != 8 || p->accumulate || p->Cog % 8 != 0 || d.stride[0] != 1) return false;   // (a transposed plan with stride 1 is a padded correlation: same kernel)
+  if (p->CB != 8 || p->accumulate || p->chunk_launches || p->Cog % 8 != 0 || d.stride[0] != 1) return false;   // (a transposed plan with stride 1 is a padded correlation: same kernel)
   if (((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 >= ((int64_t)1 << 32)) return false;
   return true;
 }
@@ -700,6 +711,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
+    a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)p.debug_stamps;
     if (p.pers_nb) {
       fc::Conv1dPersArgs pa;
@@ -710,6 +722,16 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     }
     const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;
     if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
+    const int n_ichunks = p.Cig_pad / p.CB;
+    if (p.chunk_launches) {
+      for (int ic = 0; ic < n_ichunks; ++ic) {
+        a.ic_begin = ic; a.ic_end = ic + 1; a.add_out = ic > 0;
+        if (ic > 0) a.bias = nullptr;
+        FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
+      }
+      return FC_OK;
+    }
+    a.ic_begin = 0; a.ic_end = n_ichunks; a.add_out = 0;
     FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
     return FC_OK;
   }

@@ -388,3 +388,25 @@ def test_large_grouped_dilated_rows_sampled():
         worst = max(worst, abs(got - want) / max(1.0, abs(want)))
     print(f"large rows: worst sampled error {worst:.2e}")
     assert worst < REL_TOL
+
+
+def test_long_dilated_kernel_with_many_channels_forward_and_backward():
+    """Dilated extent 2098 needs the 4096 tile, which has no room for the running sums of a second input
+    chunk: the plan launches the general kernel once per chunk (later chunks add into y).  The backward of
+    a 4 -> 16 convolution needs exactly that for dX (16 'input' channels of the transposed plan)."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(31)
+    for cin, cout in ((4, 16), (20, 8)):
+        x = torch.randn(2, cin, 5317, generator=gen, dtype=torch.float64)
+        w = torch.randn(cout, cin, 700, generator=gen, dtype=torch.float64) / (700 * cin) ** 0.5
+        b = torch.randn(cout, generator=gen, dtype=torch.float64)
+        xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+        want = F.conv1d(xr, wr, br, dilation=3, padding=100)
+        xd, wd, bd = (t.float().to(DEV).requires_grad_() for t in (x, w, b))
+        got = fft_conv(xd, wd, bias=bd, dilation=3, padding=100)
+        gy = torch.randn(want.shape, generator=gen, dtype=torch.float64)
+        want.backward(gy)
+        got.backward(gy.float().to(DEV))
+        for a_, b_ in ((got, want), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+            err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
+            assert err < REL_TOL, (cin, cout, err)

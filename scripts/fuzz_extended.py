@@ -46,3 +46,42 @@ for ndim, count in counts.items():
             sys.exit(1)
         worst = max(worst, max(errs))
 print(f"extended fuzz seed {seed}: worst rel err {worst:.2e}")
+
+# transposed convolutions
+import torch.nn.functional as F  # noqa: E402
+from fft_conv_pytorch_amd.functional import fft_conv_transpose  # noqa: E402
+worst_t = 0.0
+for ndim, count in {1: 80, 2: 30, 3: 12}.items():
+    rng = random.Random(seed * 333 + ndim)
+    gen = torch.Generator().manual_seed(seed * 5 + ndim)
+    convt = getattr(F, f"conv_transpose{ndim}d")
+    for n in range(count):
+        groups = rng.choice([1, 1, 2])
+        cig, cog = rng.choice([1, 2, 4, 8, 9, 16]), rng.choice([1, 3, 8, 16])
+        batch = rng.choice([1, 2, 3, 5, 8])
+        k = rng.choice([1, 2, 3, 5, 33 if ndim == 1 else 4, 200 if ndim == 1 else 2])
+        stride = rng.choice([1, 1, 2, 3])
+        dil = rng.choice([1, 2, 3])
+        pad = rng.choice([0, 1, (k - 1) * dil // 2])
+        opad = rng.randint(0, max(stride, dil) - 1)
+        size = [rng.randint(2, {1: 4000, 2: 60, 3: 14}[ndim]) for _ in range(ndim)]
+        kw = dict(stride=stride, padding=pad, output_padding=opad, dilation=dil, groups=groups)
+        print("T", ndim, n, batch, cig * groups, cog * groups, k, size, kw, flush=True)
+        x = torch.randn(batch, cig * groups, *size, generator=gen, dtype=torch.float64)
+        w = torch.randn(cig * groups, cog, *([k] * ndim), generator=gen, dtype=torch.float64)
+        b = torch.randn(cog * groups, generator=gen, dtype=torch.float64)
+        try:
+            want = convt(x, w, b, **kw)
+        except RuntimeError:
+            continue
+        try:
+            got = fft_conv_transpose(x.float().to("cuda"), w.float().to("cuda"), b.float().to("cuda"), **kw)
+        except NotImplementedError as exc:
+            print("  unsupported:", str(exc)[:120], flush=True)
+            continue
+        err = tf._rel(got, want)
+        if got.shape != want.shape or err >= 1e-4:
+            print("MISMATCH", err, flush=True)
+            sys.exit(1)
+        worst_t = max(worst_t, err)
+print(f"extended transposed fuzz seed {seed}: worst rel err {worst_t:.2e}")

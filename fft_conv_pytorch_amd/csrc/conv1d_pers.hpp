@@ -9,10 +9,13 @@
 //   * the NB batch items of an item share every kernel-spectrum load of the mix step, which is what
 //     bounds the one-item-per-workgroup kernel (L2 -> L1 traffic of the spectrum);
 //   * the pass-A twiddle table lives in LDS for the lifetime of the workgroup;
-//   * the mix streams the spectrum through a two-deep register pipeline (loads of step s+1 are in
-//     flight while step s is contracted).
-// Fast-path restrictions (everything else runs conv1d_fused_kernel): a single input-channel chunk
-// (Cin/groups <= CIB), full output chunks (Cout/groups a multiple of CIB) and stride 1.
+//   * the mix streams the spectrum through two register sets that are both in flight (set A holds step
+//     s, set B step s+1; each is refilled with step s+2 right after use); the first two sets of an item
+//     are requested before the barrier in front of the mix;
+//   * with PHASES a dilation d runs as d interleaved phases on the batch-sharing axis (virtual batch
+//     B*d against the undilated kernel spectrum).
+// Fast-path restrictions (everything else runs conv1d_wide_kernel or conv1d_fused_kernel): a single
+// input-channel chunk (Cin/groups <= CIB), full output chunks (Cout/groups a multiple of CIB), stride 1.
 #pragma once
 #include "conv1d_fused.hpp"
 

@@ -486,9 +486,6 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
       if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampc(1); }
       fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA, twB);
     }
-    stampc(2);
-    __syncthreads();
-    stampc(3);
     // mix: every bin is independent in complex mode.  step = (bin of this thread, output channel o);
     // two register sets alternate so the CIB/2 spectrum loads of the next step are in flight while
     // this one is contracted for all NB batch items (same scheme as the 1-D kernel).
@@ -539,7 +536,10 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
           }
         }
       };
-      if (nsteps > 0) issue(0, 0, wA);
+      if (nsteps > 0) issue(0, 0, wA);      // does not depend on the transforms: travels across the barrier
+      stampc(2);
+      __syncthreads();
+      stampc(3);
       if (R > 1) {
         // several threads (in different waves) read a bin that others overwrite in place
         load_x(0);

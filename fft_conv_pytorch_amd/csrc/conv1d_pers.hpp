@@ -35,7 +35,7 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false>
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -161,9 +161,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
       }
     };
-    f4 wA[2 * NPI], wB[2 * NPI];
-    issue(0, 0, wA);
-    issue(0, 1, wB);
+    // RING register sets: step s lives in set s % RING; the first RING steps are requested here
+    // (RING = 3 fits in 244 VGPRs at NB = 4 but measured no faster than 2: 37.4 vs 36.9 us at cfgA)
+    f4 wr[RING][2 * NPI];
+    static_for<0, RING>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < BP * NPI) issue(s / NPI, s % NPI, wr[s]);
+    });
     stamp_item(a.stamps, it, 4);
     __syncthreads();
     stamp_item(a.stamps, it, 5);
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           }
         }
       };
-#pragma unroll 1
-      for (int m = 0; m < BP; ++m) {
+      static_for<0, BP>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
         const int f = tid + m * NT;
         const int fm = (T - f) & (T - 1);
         {
@@ -218,16 +222,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
               xo[b][p] = sub_conj_divi(zf, zg);
             }
         }
-#pragma unroll
-        for (int q = 0; q < NPI; q += 2) {
-          contract(f, fm, q, wA);
-          if (q + 2 < NPI) issue(m, q + 2, wA);
-          else if (m + 1 < BP) issue(m + 1, 0, wA);
-          contract(f, fm, q + 1, wB);
-          if (q + 3 < NPI) issue(m, q + 3, wB);
-          else if (m + 1 < BP) issue(m + 1, 1, wB);
-        }
-      }
+        static_for<0, NPI>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int s = m * NPI + q;               // this step; its set is refilled with step s + RING
+          contract(f, fm, q, wr[s % RING]);
+          if constexpr (s + RING < BP * NPI) issue((s + RING) / NPI, (s + RING) % NPI, wr[s % RING]);
+        });
+      });
       if (sb_act) {
         float acc = 0.f;
 #pragma unroll

@@ -124,7 +124,6 @@ def main():
             dist.init_process_group(backend)
 
     import fft_conv_pytorch_amd as fca
-    from fft_conv_pytorch_amd import _native
 
     cfg = CONFIGS[args.config]
     ndim, batch, cin, cout, groups, spatial, kernel, dil = cfg

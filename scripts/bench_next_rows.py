@@ -7,7 +7,6 @@ import argparse
 import json
 import os
 import sys
-import time
 
 import torch
 import torch.nn.functional as F

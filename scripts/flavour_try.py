@@ -1,5 +1,5 @@
 """Parity + timing of one batch-sharing kernel flavour (FFTCONV_PERS / FFTCONV_TILE from the environment)."""
-import os, sys, time
+import os, sys
 import torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 2
+#define FC_ABI_VERSION 3
 
 enum fc_status {
   FC_OK = 0,

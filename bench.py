@@ -169,8 +169,7 @@ def main():
     steps, warmup = args.steps, args.warmup
     graph = None
     if not args.no_graph:
-        # one rotation over the buffer sets per graph; steps is rounded to whole rotations
-        steps = max(nbuf, (steps // nbuf) * nbuf)
+        # one rotation over the buffer sets per graph; a remainder of steps is launched eagerly
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(stream)
         with torch.cuda.stream(side):

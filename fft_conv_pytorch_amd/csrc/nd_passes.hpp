@@ -84,6 +84,25 @@ __device__ __forceinline__ int inv_to_regs(f2 (&v)[G::P], f2* lseq, int tseq, bo
   return j;
 }
 
+// same with the pass-A twiddles already requested by the caller (at kernel start, so that their L2 round
+// trip hides behind the data loads instead of following the barrier in front of the inverse)
+template <class G>
+__device__ __forceinline__ int inv_to_regs_pre(f2 (&v)[G::P], const f2 (&w)[G::P], f2* lseq, int tseq, bool act, BufRsrc twB) {
+  if (act) nat_load<G>(v, lseq, tseq);
+  seq_sync<G>();
+  if (act) {
+    fft_regs<G::P, +1>(v);
+    passA_twiddle_apply<G, +1>(v, w, lseq, tseq);
+  }
+  seq_sync<G>();
+  int j = 0;
+  if (act) {
+    passB_load<G>(v, lseq, tseq);
+    j = passB_compute<G, +1>(v, tseq, twB);
+  }
+  return j;
+}
+
 template <class G>
 struct SeqLayout {
   // sequence stride in LDS: == 2 (mod 32) complex slots so that 16 neighbouring sequences read
@@ -284,6 +303,8 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   const int img = id / a.NC;
   const int bn0 = bb * NSEQ;
   const bool act = bn0 + sq < a.NB;
+  f2 wtw[P];
+  passA_twiddle_fetch<G>(wtw, tseq, twA);      // requested first: lands while the spectra are loaded
   {
     const f2* in = a.src + (size_t)img * a.sa + (size_t)c * a.sc + bn0;
     for (int idx = tid; idx < T * NSEQ; idx += NT) {
@@ -293,7 +314,7 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   }
   __syncthreads();
   f2 v[P];
-  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
+  const int j = inv_to_regs_pre<G>(v, wtw, lds + sq * LSEQP, tseq, act, twB);
   if (act) {
     f2* out = a.dst + (size_t)img * a.ta + (size_t)(bn0 + sq) * a.tb + (size_t)c * a.tc;
     const int nbase = (tseq >> G::LGS) + P * P * j;
@@ -334,6 +355,8 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   const int c = id % a.NC;
   const int img = id / a.NC;
   const int y0 = yb * RB;
+  f2 wtw[P];
+  passA_twiddle_fetch<G>(wtw, tseq, twA);      // requested first: lands while the spectra are loaded
   {
     // rows 2s (-> real part) and 2s+1 (-> imaginary part) share one complex inverse FFT:
     // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
@@ -379,7 +402,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   }
   __syncthreads();
   f2 v[P];
-  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
+  const int j = inv_to_regs_pre<G>(v, wtw, lds + sq * LSEQP, tseq, true, twB);
   const int ya_row = y0 + 2 * sq;
   const float b = a.bias ? a.bias[img % a.Cout] : 0.f;
   float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;

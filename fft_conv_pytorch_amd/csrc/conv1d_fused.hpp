@@ -38,6 +38,8 @@ struct Conv1dArgs {
   int L, pad, pad_mode;  // source row length, left padding (may be negative for a transposed plan)
   int up;                // transposed plan: the source is spread over a grid of this step (zeros between)
   int ph;                // batch-sharing kernel: dilation run as `ph` interleaved phases (virtual batch B*ph), else 1
+  int slot_tiles;        // batch-sharing kernel: the slots of a work item are consecutive TILES of one (virtual) batch
+                         // item instead of consecutive batch items of one tile
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when this launch covers several input chunks (separate output region in LDS)
   int ic_begin, ic_end;  // input chunks of this launch (all of them unless the plan launches chunk by chunk)

@@ -71,10 +71,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   // the batch-sharing axis as a virtual batch of B*d items (slot vb -> batch vb / d, phase vb % d).
   auto fetch = [&](const WorkItem& wi, f2 (&v)[P]) {
     const int g = wi.goc / a.n_ochunks;
-    const int vb = wi.b0 + nb;
-    const int bfirst = wi.b0 / nph, blast = (wi.b0 + wi.nbc - 1) / nph;
+    const int vb = a.slot_tiles ? wi.b0 : wi.b0 + nb;
+    const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
+    const int bfirst = wi.b0 / nph, blast = a.slot_tiles ? bfirst : (wi.b0 + wi.nbc - 1) / nph;
     const int b = vb / nph, phase = vb - b * nph;
-    const int pos0 = wi.tile * a.V * nph + phase - a.pad;          // source position of the tile's first sample
+    const int pos0 = tile * a.V * nph + phase - a.pad;             // source position of the tile's first sample
     const bool interior = (pos0 >= 0) && (pos0 + (T - 1) * nph < a.L);
     const bool act_in = nb < wi.nbc;
     const float* xbase = a.x + ((size_t)bfirst * a.Cin + (size_t)g * a.Cig) * a.L;
@@ -257,9 +258,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       passB_load<G>(v, zseq, tseq);
       const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;
-      const int vb = wi.b0 + nb;
+      const int vb = a.slot_tiles ? wi.b0 : wi.b0 + nb;
+      const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
       const int b = vb / nph, phase = vb - b * nph;
-      const int t0 = wi.tile * a.V;                                   // in samples of this phase
+      const int t0 = tile * a.V;                                      // in samples of this phase
       const int limit = min(a.V, (a.Lfull - phase + nph - 1) / nph - t0);
       const int nbase = o1 + P * P * j;
       float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase) * nph + phase;

@@ -125,6 +125,7 @@ struct fc_plan {
   int pers_grid, pers_items;
   int chunk_launches;         // general kernel launched once per input chunk, later chunks add into y (see plan_1d)
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
+  int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
 };
@@ -264,6 +265,7 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
                         {2048, 2, 1, 19.5}, {1024, 2, 2, 16.0}, {1024, 4, 1, 15.0}};
   double best = 0;
   int best_T = 0, best_nb = 0, best_ph = 1;
+  bool best_tiles = false;
   // second round: dilation d as d phases of a virtual batch B*d against the undilated kernel
   const int rounds = (fast_ok && d.dilation[0] > 1) ? 2 : 1;
   for (int round = 0; round < rounds; ++round) {
@@ -274,21 +276,27 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
     for (const Cand& c : cands) {
       if (round && c.nb == 0) continue;               // only the batch-sharing kernel knows phases
       if (c.T < Kd || p->accumulate) continue;
-      if (c.nb != 0 && (!fast_ok || c.nb > B)) continue;
+      if (c.nb != 0 && !fast_ok) continue;
       if (want > 0 && c.nb != want) continue;
       const int64_t V = c.T - Kd + 1;
       if (V * 4 < c.T) continue;                      // less than a quarter of the tile useful: leave to the cost model
       const int64_t nt = (Lfull + V - 1) / V;
-      const int64_t items = ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt * per_item_units;
+      // fewer batch items than slots: the slots of a work item become consecutive TILES of one batch item
+      // (they share the spectrum just the same); measured 1.3-1.6x on batch-1 rows of 2^20 samples
+      const bool by_tiles = c.nb > B;
+      if (by_tiles && nt < c.nb) continue;
+      const int64_t groups_of = by_tiles ? B * ((nt + c.nb - 1) / c.nb) : ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt;
+      const int64_t items = groups_of * per_item_units;
       const int64_t slots = (int64_t)cus * c.wgs_per_cu;
       const double est = (double)((items + slots - 1) / slots) * c.t_item;
-      if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; best_ph = ph; }
+      if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; best_ph = ph; best_tiles = by_tiles; }
     }
   }
   if (best_T == 0) return FC_OK;                    // general planner (cost model) decides
   *tile_out = best_T;
   p->pers_nb_choice = best_nb;
   p->ph = best_ph;
+  p->slot_tiles = best_tiles ? 1 : 0;
   return FC_OK;
 }
 
@@ -335,9 +343,31 @@ static int plan_1d_persistent(fc_plan* p) {
         if ((pass == 0) == !interior) tile_order.push_back(tile);
       }
   }
+  {
+    const char* env = getenv("FFTCONV_SLOTS");      // "tiles" / "batch": overrides the planner's choice
+    if (env) p->slot_tiles = env[0] == 't' ? 1 : 0;
+    if (p->wide) p->slot_tiles = 0;
+  }
+  auto is_border = [&](int tile) {
+    const int64_t pos = (int64_t)tile * p->V * p->ph - p->padl[0];
+    return !(p->up[0] == 1 && pos >= 0 && pos + (int64_t)(t->T - 1) * p->ph + p->ph <= d.spatial[0]);
+  };
+  if (p->slot_tiles) {
+    // slots = consecutive tiles of one (virtual) batch item: chunks that touch a border tile go first
+    for (int pass = 0; pass < 2; ++pass)
+      for (int64_t vb = 0; vb < B; ++vb)
+        for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
+          for (int t0 = 0; t0 < p->ntiles; t0 += nb) {
+            const int n = std::min(nb, p->ntiles - t0);
+            bool border = false;
+            for (int k = 0; k < n; ++k) border |= is_border(t0 + k);
+            if ((pass == 0) == border) items.push_back({(int)vb, n, t0, goc});
+          }
+  } else {
   for (int tile : tile_order)
     for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
       for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
+  }
   if (nb >= 2 && (int64_t)items.size() > slots) {
     const int64_t tail = (int64_t)items.size() % slots;
     if (tail > 0 && tail <= slots / 2) {
@@ -345,14 +375,16 @@ static int plan_1d_persistent(fc_plan* p) {
       for (int64_t k = (int64_t)items.size() - tail; k < (int64_t)items.size(); ++k) {
         const fc::WorkItem w = items[k];
         const int h = w.nbc / 2;
+        if (h == 0) { split.push_back(w); continue; }
         split.push_back({w.b0, h, w.tile, w.goc});
-        split.push_back({w.b0 + h, w.nbc - h, w.tile, w.goc});
+        if (p->slot_tiles) split.push_back({w.b0, w.nbc - h, w.tile + h, w.goc});
+        else split.push_back({w.b0 + h, w.nbc - h, w.tile, w.goc});
       }
       items.resize(items.size() - tail);
       items.insert(items.end(), split.begin(), split.end());
     }
   }
-  if (rem)
+  if (rem && !p->slot_tiles)
     for (int tile = 0; tile < p->ntiles; ++tile)
       for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) items.push_back({nfull * nb, rem, tile, goc});
   if (items.size() > 0x7fffffffu) return FC_OK;
@@ -708,7 +740,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.twA = p.tw.twA; a.twB = p.tw.twB;
     a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
-    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph;
+    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph; a.slot_tiles = p.slot_tiles;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;

@@ -410,3 +410,20 @@ def test_long_dilated_kernel_with_many_channels_forward_and_backward():
         for a_, b_ in ((got, want), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
             err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
             assert err < REL_TOL, (cin, cout, err)
+
+
+@pytest.mark.parametrize("batch,mode", [(1, "constant"), (3, "reflect")])
+def test_small_batch_long_rows_use_tile_slots(batch, mode):
+    """Fewer batch items than slots of a work item: the slots become consecutive tiles of one batch item
+    (same spectrum sharing).  Long 8 -> 8 rows against torch's direct convolution in float64."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(71 + batch)
+    L, K, pad = 150001, 257, 100
+    x = torch.randn(batch, 8, L, generator=gen)
+    w = torch.randn(8, 8, K, generator=gen) / (8 * K) ** 0.5
+    b = torch.randn(8, generator=gen)
+    xp = F.pad(x.double(), [pad, pad], mode=mode) if mode != "constant" else x.double()
+    want = F.conv1d(xp, w.double(), b.double(), padding=pad if mode == "constant" else 0)
+    got = fft_conv(x.to(DEV), w.to(DEV), b.to(DEV), padding=pad, padding_mode=mode)
+    assert got.shape == want.shape
+    assert (got.double().cpu() - want).norm().item() / want.norm().item() < REL_TOL

@@ -35,7 +35,7 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2>
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -113,7 +113,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   auto run = [&](const WorkItem& wi, int it, f2 (&v)[P], bool more, const WorkItem& wnext, f2 (&vnext)[P]) {
     const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
     const bool act_in = nb < wi.nbc;
-    const BufRsrc wg = make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
+    // DIAG (depthwise): the spectrum is [channel pair][T/2] float4 = {H(2p)[f], H(2p+1)[f]}, 8 channels per block g
+    const BufRsrc wg = DIAG ? make_rsrc(a.wspec + (size_t)g * NPI * (T / 2), (unsigned)(NPI * (T / 2) * 16))
+                            : make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
     stamp_item(a.stamps, it, 0);
     // bias of this lane's two output channels, requested now and used in the last pass
     const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
@@ -136,6 +138,60 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
       for (int k = 0; k < P; ++k) dst[P * k] = v[k];
     }
+    // ------------------------------------------------ mix, depthwise: every channel meets only its own kernel
+    if constexpr (DIAG) {
+      f4 wd[BP][NPI];
+#pragma unroll
+      for (int m = 0; m < BP; ++m)
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) wd[m][p] = buf_load_f32x4(wg, (unsigned)(tid + m * NT) * 16u, p * (T / 2) * 16);
+      // self-paired bins 0 and T/2: lane (batch b, pair p, bin) of wave 0; wspec[p][0] = {Re H_e[0], Re H_e[T/2], Re H_o[0], Re H_o[T/2]}
+      const int sd_b = tid / (2 * NPI), sd_p = (tid >> 1) % NPI, sd_f = (tid & 1) ? T / 2 : 0;
+      const bool sd_act = tid < NB * NPI * 2 && sd_b < wi.nbc;
+      f4 sdw = {0.f, 0.f, 0.f, 0.f};
+      if (sd_act) sdw = buf_load_f32x4(wg, 0u, sd_p * (T / 2) * 16);
+      stamp_item(a.stamps, it, 4);
+      __syncthreads();
+      stamp_item(a.stamps, it, 5);
+      static_for<0, BP>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int f = tid + m * NT;
+        const int fm = (T - f) & (T - 1);
+        f2 xe[NB][NPI], xo[NB][NPI];
+        const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
+        static_for<0, NB>([&](auto bc) {
+          constexpr int b = decltype(bc)::value;
+          const unsigned bf = af + b * NPI * G::LSEQ * 8, bg = ag + b * NPI * G::LSEQ * 8;
+          static_for<0, NPI>([&](auto pc) {
+            constexpr int p = decltype(pc)::value;
+            xe[b][p] = lds_rd<p * G::LSEQ * 8>(bf);
+            xo[b][p] = lds_rd<p * G::LSEQ * 8>(bg);
+          });
+        });
+#pragma unroll
+        for (int b = 0; b < NB; ++b) { lds_arrive(xe[b]); lds_arrive(xo[b]); }
+        if (f != 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+            if (b < wi.nbc) {
+#pragma unroll
+              for (int p = 0; p < NPI; ++p) {
+                const f2 zf = xe[b][p], zg = xo[b][p];
+                const f2 ye = cmul(add_conj(zf, zg), wd[m][p].xy);        // 2 X_even[f] * H_even[f]
+                const f2 yo = cmul(sub_conj_divi(zf, zg), wd[m][p].zw);   // 2 X_odd[f]  * H_odd[f]
+                f2* zb = zbuf + (b * NPI + p) * G::LSEQ;
+                zb[G::nat(f)] = add_pi(ye, yo);
+                zb[G::nat(fm)] = conj_add_iconj(ye, yo);
+              }
+            }
+        }
+      });
+      if (sd_act) {
+        f2* zp = zbuf + (sd_b * NPI + sd_p) * G::LSEQ + G::nat(sd_f);
+        const f2 z = *zp;
+        *zp = mk2(2.f * z.x * ((tid & 1) ? sdw.y : sdw.x), 2.f * z.y * ((tid & 1) ? sdw.w : sdw.z));
+      }
+    } else {
     // ------------------------------------------------ mix
     // The first two spectrum sets (and the self-paired bins' weights) do not depend on this item's
     // transforms: they are requested BEFORE the barrier and travel while the slower waves finish.
@@ -241,6 +297,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         *dstf = acc;
       }
     }
+    }   // dense / depthwise mix
     stamp_item(a.stamps, it, 6);
     __syncthreads();
     stamp_item(a.stamps, it, 7);

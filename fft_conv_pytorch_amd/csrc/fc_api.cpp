@@ -125,6 +125,8 @@ struct fc_plan {
   int pers_grid, pers_items;
   int chunk_launches;         // general kernel launched once per input chunk, later chunks add into y (see plan_1d)
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
+  int diag;                   // depthwise (groups == Cin == Cout, multiple of 8): 8-channel blocks, per-channel mix
+  int G;                      // channel groups as the 1-D kernels see them (C/8 blocks for a depthwise plan)
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
@@ -137,10 +139,44 @@ int fc_version(void) { return FC_ABI_VERSION; }
 const char* fc_last_error(void) { return g_err.c_str(); }
 
 static int plan_1d_persistent(fc_plan* p);
+static void set_channel_layout(fc_plan* p, int G, int Cig, int Cog);
 static int choose_fast_path(fc_plan* p, int* tile_out);
 static bool fast_path_eligible(const fc_plan* p);
 
+static void set_channel_layout(fc_plan* p, int G, int Cig, int Cog) {
+  p->G = G; p->Cig = Cig; p->Cog = Cog;
+  const int cmax = std::max(Cig, Cog);
+  p->CB = cmax <= 2 ? 2 : (cmax <= 4 ? 4 : 8);
+  p->Cig_pad = (int)round_up(Cig, p->CB);
+  p->cob = std::min(p->CB, (int)round_up(Cog, 2));
+  p->Cog_pad = (int)round_up(Cog, p->cob);
+  p->n_ochunks = p->Cog_pad / p->cob;
+  p->accumulate = p->Cig_pad > p->CB;
+}
+
+static int plan_1d_inner(fc_plan* p);
+
+// Depthwise rows (groups == Cin == Cout, a multiple of 8, stride 1) run on the batch-sharing kernel as blocks of
+// 8 channels with a per-channel mix; when that kernel cannot take the shape the generic grouped plan is used.
 static int plan_1d(fc_plan* p) {
+  const fc_desc& d = p->d;
+  const char* env = getenv("FFTCONV_DIAG");
+  const bool want = !env || atoi(env) != 0;
+  p->diag = 0;
+  if (want && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 && d.stride[0] == 1 &&
+      !(d.tile_hint && !getenv("FFTCONV_PERS"))) {
+    p->diag = 1;
+    set_channel_layout(p, (int)(d.groups / 8), 8, 8);
+    const int rc = plan_1d_inner(p);
+    if (rc == FC_OK && p->pers_nb != 0) return FC_OK;
+    if (p->d_items) { (void)hipFree(p->d_items); p->d_items = nullptr; }
+    p->diag = 0;
+    set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
+  }
+  return plan_1d_inner(p);
+}
+
+static int plan_1d_inner(fc_plan* p) {
   const fc_desc& d = p->d;
   const int64_t L = d.spatial[0], Kd = p->kd[0];
   const int64_t Lfull = p->Lf[0];
@@ -227,7 +263,7 @@ static int plan_1d(fc_plan* p) {
   const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(fc::f4);
   if (per_group >= ((size_t)1 << 32))
     return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
-  p->spectrum_bytes = per_group * (size_t)d.groups;
+  p->spectrum_bytes = p->diag ? (size_t)(d.in_channels / 2) * (best->T / 2) * sizeof(fc::f4) : per_group * (size_t)p->G;
   p->workspace_bytes = 0;
   int rc = get_twiddles(best, &p->tw);
   if (rc != FC_OK) return rc;
@@ -258,7 +294,7 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   int dev = 0, cus = 256;
   FC_HIP(hipGetDevice(&dev));
   FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  const int64_t per_item_units = (int64_t)p->n_ochunks * d.groups;
+  const int64_t per_item_units = (int64_t)p->n_ochunks * p->G;
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
   const Cand cands[] = {{256, 0, 8, 11.7}, {512, 0, 6, 17.0}, {1024, 0, 4, 25.5}, {2048, 0, 2, 28.9},
@@ -274,7 +310,7 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
     const int64_t Lfull = (p->Lf[0] + ph - 1) / ph;
     const int64_t B = d.batch * ph;
     for (const Cand& c : cands) {
-      if (round && c.nb == 0) continue;               // only the batch-sharing kernel knows phases
+      if ((round || p->diag) && c.nb == 0) continue;  // only the batch-sharing kernel knows phases / depthwise blocks
       if (c.T < Kd || p->accumulate) continue;
       if (c.nb != 0 && !fast_ok) continue;
       if (want > 0 && c.nb != want) continue;
@@ -356,7 +392,7 @@ static int plan_1d_persistent(fc_plan* p) {
     // slots = consecutive tiles of one (virtual) batch item: chunks that touch a border tile go first
     for (int pass = 0; pass < 2; ++pass)
       for (int64_t vb = 0; vb < B; ++vb)
-        for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
+        for (int goc = 0; goc < p->n_ochunks * p->G; ++goc)
           for (int t0 = 0; t0 < p->ntiles; t0 += nb) {
             const int n = std::min(nb, p->ntiles - t0);
             bool border = false;
@@ -365,7 +401,7 @@ static int plan_1d_persistent(fc_plan* p) {
           }
   } else {
   for (int tile : tile_order)
-    for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc)
+    for (int goc = 0; goc < p->n_ochunks * p->G; ++goc)
       for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
   }
   if (nb >= 2 && (int64_t)items.size() > slots) {
@@ -386,7 +422,7 @@ static int plan_1d_persistent(fc_plan* p) {
   }
   if (rem && !p->slot_tiles)
     for (int tile = 0; tile < p->ntiles; ++tile)
-      for (int goc = 0; goc < p->n_ochunks * (int)d.groups; ++goc) items.push_back({nfull * nb, rem, tile, goc});
+      for (int goc = 0; goc < p->n_ochunks * p->G; ++goc) items.push_back({nfull * nb, rem, tile, goc});
   if (items.size() > 0x7fffffffu) return FC_OK;
   p->pers_items = (int)items.size();
   // up to two items per workgroup (the second one's input is prefetched): item i and i + grid
@@ -547,15 +583,7 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
                   (long long)d.padding[i], (long long)d.spatial[i]);
     }
   }
-  p->Cig = (int)(d.in_channels / d.groups);
-  p->Cog = (int)(d.out_channels / d.groups);
-  const int cmax = std::max(p->Cig, p->Cog);
-  p->CB = cmax <= 2 ? 2 : (cmax <= 4 ? 4 : 8);
-  p->Cig_pad = (int)round_up(p->Cig, p->CB);
-  p->cob = std::min(p->CB, (int)round_up(p->Cog, 2));
-  p->Cog_pad = (int)round_up(p->Cog, p->cob);
-  p->n_ochunks = p->Cog_pad / p->cob;
-  p->accumulate = p->Cig_pad > p->CB;
+  set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
 
   int rc;
   if (d.ndim == 1) rc = plan_1d(p);
@@ -661,7 +689,7 @@ long long fc_debug_grid(const fc_plan* plan) {
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
   }
   if (plan->pers_nb) return plan->pers_items;
-  return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->d.groups;
+  return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->G;
 }
 
 int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, void* workspace, void* hip_stream) {
@@ -675,7 +703,10 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.wspec = (fc::f4*)w_hat;
     a.twA = p.tw.twA;
     a.twB = p.tw.twB;
-    a.G = (int)p.d.groups; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
+    a.G = p.G; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
+    if (p.diag) {   // depthwise: (C, 1, K) read as one output row over C inputs -> [C/2 pairs][T/2] float4
+      a.G = 1; a.Cog = 1; a.Cog_pad = 1; a.Cig = (int)p.d.in_channels; a.Cig_pad = a.Cig;
+    }
     a.K = (int)p.d.kernel[0]; a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
     a.transposed = p.d.transposed;
@@ -738,9 +769,9 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     fc::Conv1dArgs a;
     a.x = x; a.wspec = (const fc::f4*)w_hat; a.bias = p.d.has_bias ? bias : nullptr; a.y = y;
     a.twA = p.tw.twA; a.twB = p.tw.twB;
-    a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
+    a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = p.G;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
-    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph; a.slot_tiles = p.slot_tiles;
+    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph; a.slot_tiles = p.slot_tiles; a.diag = p.diag;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;

@@ -170,27 +170,30 @@ constexpr int kPersNb0 = 0, kPersNb1 = 0;
 #endif
 constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_t)nb * 4 * GG::LSEQ) * sizeof(float2); }
 
+// batch-sharing kernel builds: PHASES (dilation as phases) x DIAG (depthwise blocks); the plain one keeps its
+// immediate offsets and is the only one the headline configuration runs
+template <int NB, bool PHASES, bool DIAG>
+hipError_t launch_pers_variant(const Conv1dPersArgs& a, int grid, hipStream_t st) {
+  constexpr int NT = NB * 4 * GG::TS;
+  const size_t lds = pers_lds_bytes(NB);
+  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG>;
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
+
 template <int NB>
 hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   if constexpr (NB == 0) {
     return hipErrorInvalidValue;
   } else {
-    constexpr int NT = NB * 4 * GG::TS;
-    const size_t lds = pers_lds_bytes(NB);
-    if (a.c.ph > 1) {            // dilation as phases: separate build so the plain kernel keeps its immediates
-      auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, true>;
-      static bool done = false;
-      hipError_t e = ensure_lds(k, lds, &done);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
-      return hipGetLastError();
-    }
-    auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, false>;
-    static bool done = false;
-    hipError_t e = ensure_lds(k, lds, &done);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
-    return hipGetLastError();
+    const bool ph = a.c.ph > 1, dg = a.c.diag != 0;
+    if (ph && dg) return launch_pers_variant<NB, true, true>(a, grid, st);
+    if (ph) return launch_pers_variant<NB, true, false>(a, grid, st);
+    if (dg) return launch_pers_variant<NB, false, true>(a, grid, st);
+    return launch_pers_variant<NB, false, false>(a, grid, st);
   }
 }
 

@@ -427,3 +427,36 @@ def test_small_batch_long_rows_use_tile_slots(batch, mode):
     got = fft_conv(x.to(DEV), w.to(DEV), b.to(DEV), padding=pad, padding_mode=mode)
     assert got.shape == want.shape
     assert (got.double().cpu() - want).norm().item() / want.norm().item() < REL_TOL
+
+
+DEPTHWISE_CASES = [  # B, C, L, K, padding, dilation, mode
+    (8, 64, 20000, 1025, 0, 1, "constant"),
+    (3, 24, 5000, 33, 5, 1, "reflect"),
+    (1, 8, 100000, 257, 0, 1, "constant"),       # batch 1: tile slots
+    (5, 16, 9000, 129, 64, 3, "circular"),       # dilation as phases on depthwise blocks
+    (2, 40, 3000, 700, 10, 1, "replicate"),
+    (4, 12, 2000, 65, 0, 1, "constant"),         # 12 channels: not a multiple of 8 -> generic grouped plan
+]
+
+
+@pytest.mark.parametrize("case", DEPTHWISE_CASES)
+def test_depthwise_blocks(case):
+    """groups == channels: 8-channel blocks on the batch-sharing kernel with a per-channel mix; forward,
+    transposed (dX) and weight gradient against torch's direct convolution in float64."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    B, C, L, K, pad, dil, mode = case
+    gen = torch.Generator().manual_seed(900 + C + K)
+    x = torch.randn(B, C, L, generator=gen, dtype=torch.float64)
+    w = torch.randn(C, 1, K, generator=gen, dtype=torch.float64) / K ** 0.5
+    b = torch.randn(C, generator=gen, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    xp = F.pad(xr, [pad, pad], mode=mode) if (mode != "constant" and pad) else xr
+    want = F.conv1d(xp, wr, br, padding=pad if mode == "constant" else 0, dilation=dil, groups=C)
+    xd, wd, bd = (t.float().to(DEV).requires_grad_() for t in (x, w, b))
+    got = fft_conv(xd, wd, bias=bd, padding=pad, dilation=dil, groups=C, padding_mode=mode)
+    gy = torch.randn(want.shape, generator=gen, dtype=torch.float64)
+    want.backward(gy)
+    got.backward(gy.float().to(DEV))
+    for a_, b_ in ((got, want), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
+        assert err < REL_TOL, (case, err)

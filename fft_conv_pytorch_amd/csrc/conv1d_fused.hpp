@@ -44,6 +44,8 @@ struct Conv1dArgs {
   int Kd, V, ntiles, Lfull, Lout, stride;
   int accumulate;        // 1 when this launch covers several input chunks (separate output region in LDS)
   int ic_begin, ic_end;  // input chunks of this launch (all of them unless the plan launches chunk by chunk)
+  int segmented;         // the plan runs the kernel in segments of taps (pos_shift / add_out vary per launch)
+  int pos_shift;         // kernel segment: its first tap sits this many samples into the (dilated) kernel
   int add_out;           // 1: y += result (later chunk launches of such a plan; bias went with the first)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
 };
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
   f2* zin = lds;
   f2* vout = a.accumulate ? lds + NPI * G::LSEQ : lds;
 
-  const int tile_pos = tile * a.V - a.pad;     // signal coordinate of tile sample 0
+  const int tile_pos = tile * a.V - a.pad + a.pos_shift;     // signal coordinate of tile sample 0
   const bool interior = a.up == 1 && (tile_pos >= 0) && (tile_pos + T <= a.L);
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   // buffer descriptors from uniform values only (no waterfall loops)

@@ -35,7 +35,7 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)item * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false>
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
     const int bfirst = wi.b0 / nph, blast = a.slot_tiles ? bfirst : (wi.b0 + wi.nbc - 1) / nph;
     const int b = vb / nph, phase = vb - b * nph;
-    const int pos0 = tile * a.V * nph + phase - a.pad;             // source position of the tile's first sample
+    const int pos0 = tile * a.V * nph + phase - a.pad + (SEG ? a.pos_shift : 0);   // source position of the tile's first sample
     const bool interior = (pos0 >= 0) && (pos0 + (T - 1) * nph < a.L);
     const bool act_in = nb < wi.nbc;
     const float* xbase = a.x + ((size_t)bfirst * a.Cin + (size_t)g * a.Cig) * a.L;
@@ -323,7 +323,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       const int nbase = o1 + P * P * j;
       float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase) * nph + phase;
       float* y1 = y0 + a.Lout;
-      if (!PHASES) {
+      if (SEG && a.add_out) {
+        // later segments of a long kernel accumulate into the output of the first
+        const int ystep = P * nph;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) { y0[ystep * k] += v[k].x; y1[ystep * k] += v[k].y; }
+      } else if (!PHASES) {
 #pragma unroll
         for (int k = 0; k < P; ++k)
           if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }

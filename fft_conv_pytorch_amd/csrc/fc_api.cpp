@@ -125,6 +125,9 @@ struct fc_plan {
   int pers_grid, pers_items;
   int chunk_launches;         // general kernel launched once per input chunk, later chunks add into y (see plan_1d)
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
+  int nseg, seg_taps;         // 1-D: the kernel runs in nseg segments of seg_taps taps (1 = whole kernel)
+  int64_t kd_plan;            // dilated extent the tiles are planned for (of one segment)
+  size_t seg_spectrum_bytes;  // kernel-spectrum bytes of one segment
   int diag;                   // depthwise (groups == Cin == Cout, multiple of 8): 8-channel blocks, per-channel mix
   int G;                      // channel groups as the 1-D kernels see them (C/8 blocks for a depthwise plan)
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
@@ -178,7 +181,21 @@ static int plan_1d(fc_plan* p) {
 
 static int plan_1d_inner(fc_plan* p) {
   const fc_desc& d = p->d;
-  const int64_t L = d.spatial[0], Kd = p->kd[0];
+  // Long kernels run in segments of taps: segment j is the convolution with taps [j*Ks, (j+1)*Ks) read
+  // j*Ks*dilation samples further into the row, later segments add into y.  This lifts the 4096-point tile
+  // limit on the dilated extent and keeps 8-channel shapes on the batch-sharing kernel beyond its 2048 tile.
+  p->nseg = 1; p->seg_taps = (int)d.kernel[0]; p->kd_plan = p->kd[0];
+  {
+    const bool sharing_shape = p->CB == 8 && p->Cog % 8 == 0 && d.stride[0] == 1;
+    const bool want_seg = p->kd[0] > 4096 || (sharing_shape && p->kd[0] > 1537 && !d.tile_hint);
+    if (want_seg) {
+      const int64_t ks = std::max<int64_t>(1, 1024 / d.dilation[0] + 1);       // (ks - 1) * dilation + 1 <= 1025
+      p->seg_taps = (int)std::min<int64_t>(ks, d.kernel[0]);
+      p->nseg = (int)((d.kernel[0] + p->seg_taps - 1) / p->seg_taps);
+      p->kd_plan = (int64_t)(p->seg_taps - 1) * d.dilation[0] + 1;
+    }
+  }
+  const int64_t L = d.spatial[0], Kd = p->kd_plan;
   const int64_t Lfull = p->Lf[0];
   p->Lfull = (int)Lfull;
   if (L * (int64_t)std::max(p->Cig, 1) * 4 >= (int64_t)1 << 32)
@@ -201,7 +218,7 @@ static int plan_1d_inner(fc_plan* p) {
     // 24.6 us there vs 29.1 us here; k = 129 ... 1025: 2.0-2.5x faster here).
     const char* env = getenv("FFTCONV_WIDE");
     const int want_wide = env ? atoi(env) : 1;
-    if (want_wide && p->CB == 8 && p->accumulate && p->Cog % 8 == 0 && d.stride[0] == 1 && d.batch >= 2 &&
+    if (want_wide && p->nseg == 1 && p->CB == 8 && p->accumulate && p->Cog % 8 == 0 && d.stride[0] == 1 && d.batch >= 2 &&
         ((int64_t)d.in_channels * 3 + p->Cig) * d.spatial[0] * 4 < ((int64_t)1 << 32)) {
       const int wt = Kd < 97 ? 0 : (Kd <= 768 ? 1024 : (Kd <= 1536 ? 2048 : 0));
       if (wt && (!forced_tile || forced_tile == wt) && find_tile(wt) && find_tile(wt)->wide_nb) {
@@ -263,7 +280,8 @@ static int plan_1d_inner(fc_plan* p) {
   const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(fc::f4);
   if (per_group >= ((size_t)1 << 32))
     return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
-  p->spectrum_bytes = p->diag ? (size_t)(d.in_channels / 2) * (best->T / 2) * sizeof(fc::f4) : per_group * (size_t)p->G;
+  p->seg_spectrum_bytes = p->diag ? (size_t)(d.in_channels / 2) * (best->T / 2) * sizeof(fc::f4) : per_group * (size_t)p->G;
+  p->spectrum_bytes = p->seg_spectrum_bytes * (size_t)p->nseg;
   p->workspace_bytes = 0;
   int rc = get_twiddles(best, &p->tw);
   if (rc != FC_OK) return rc;
@@ -303,10 +321,10 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   int best_T = 0, best_nb = 0, best_ph = 1;
   bool best_tiles = false;
   // second round: dilation d as d phases of a virtual batch B*d against the undilated kernel
-  const int rounds = (fast_ok && d.dilation[0] > 1) ? 2 : 1;
+  const int rounds = (fast_ok && d.dilation[0] > 1 && p->nseg == 1) ? 2 : 1;
   for (int round = 0; round < rounds; ++round) {
     const int ph = round ? (int)d.dilation[0] : 1;
-    const int64_t Kd = round ? d.kernel[0] : p->kd[0];
+    const int64_t Kd = round ? d.kernel[0] : p->kd_plan;
     const int64_t Lfull = (p->Lf[0] + ph - 1) / ph;
     const int64_t B = d.batch * ph;
     for (const Cand& c : cands) {
@@ -707,12 +725,18 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     if (p.diag) {   // depthwise: (C, 1, K) read as one output row over C inputs -> [C/2 pairs][T/2] float4
       a.G = 1; a.Cog = 1; a.Cog_pad = 1; a.Cig = (int)p.d.in_channels; a.Cig_pad = a.Cig;
     }
-    a.K = (int)p.d.kernel[0]; a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];
+    a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
     a.transposed = p.d.transposed;
+    a.Krow = (int)p.d.kernel[0];
     const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
     const int grid = (a.nseq + per_wg - 1) / per_wg;
-    FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
+    for (int j = 0; j < p.nseg; ++j) {
+      a.k0 = j * p.seg_taps;
+      a.K = std::min(p.seg_taps, (int)p.d.kernel[0] - a.k0);
+      a.wspec = (fc::f4*)((char*)w_hat + (size_t)j * p.seg_spectrum_bytes);
+      FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
+    }
     return FC_OK;
   }
   // ---- 2-D / 3-D: the separable passes, fed from the dilated taps
@@ -776,11 +800,18 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)p.debug_stamps;
+    a.segmented = p.nseg > 1; a.pos_shift = 0;
     if (p.pers_nb) {
-      fc::Conv1dPersArgs pa;
-      pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;
-      if (p.wide) FC_HIP(p.tile->conv1d_wide(pa, p.pers_grid, st));
-      else FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
+      for (int j = 0; j < p.nseg; ++j) {
+        fc::Conv1dPersArgs pa;
+        a.pos_shift = j * p.seg_taps * (int)p.d.dilation[0];
+        a.wspec = (const fc::f4*)((const char*)w_hat + (size_t)j * p.seg_spectrum_bytes);
+        a.add_out = j > 0;
+        if (j > 0) a.bias = nullptr;
+        pa.c = a; pa.items = p.d_items; pa.n_items = p.pers_items;
+        if (p.wide) FC_HIP(p.tile->conv1d_wide(pa, p.pers_grid, st));
+        else FC_HIP(p.tile->conv1d_pers(p.pers_nb, pa, p.pers_grid, st));
+      }
       return FC_OK;
     }
     const int64_t grid = (int64_t)a.B * a.ntiles * a.n_ochunks * a.G;
@@ -794,8 +825,13 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
       }
       return FC_OK;
     }
-    a.ic_begin = 0; a.ic_end = n_ichunks; a.add_out = 0;
-    FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
+    for (int j = 0; j < p.nseg; ++j) {
+      a.pos_shift = j * p.seg_taps * (int)p.d.dilation[0];
+      a.wspec = (const fc::f4*)((const char*)w_hat + (size_t)j * p.seg_spectrum_bytes);
+      a.ic_begin = 0; a.ic_end = n_ichunks; a.add_out = j > 0;
+      if (j > 0) a.bias = nullptr;
+      FC_HIP(p.tile->conv1d(p.CB, a, (int)grid, p.lds_conv, st));
+    }
     return FC_OK;
   }
   // ---- 2-D / 3-D

@@ -19,6 +19,7 @@ struct Spec1dArgs {
   const f2* twA;
   const f2* twB;
   int G, Cig, Cog, Cig_pad, Cog_pad, K, dil, nseq;
+  int Krow, k0;        // taps per weight row and first tap of this kernel segment (K = taps of the segment)
   int transposed;      // kernel is (Cin, Cout/g, K): swap in/out inside the group and flip the taps
 };
 
@@ -44,15 +45,15 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
     f2 v[P];
     const bool has0 = act && o < a.Cog && 2 * ip < a.Cig;
     const bool has1 = act && o < a.Cog && 2 * ip + 1 < a.Cig;
-    const float* w0 = a.transposed ? a.w + ((size_t)(g * a.Cig + 2 * ip) * a.Cog + o) * a.K
-                                   : a.w + ((size_t)(g * a.Cog + o) * a.Cig + 2 * ip) * a.K;
-    const float* w1 = w0 + (a.transposed ? (size_t)a.Cog * a.K : (size_t)a.K);
+    const float* w0 = a.transposed ? a.w + ((size_t)(g * a.Cig + 2 * ip) * a.Cog + o) * a.Krow
+                                   : a.w + ((size_t)(g * a.Cog + o) * a.Cig + 2 * ip) * a.Krow;
+    const float* w1 = w0 + (a.transposed ? (size_t)a.Cog * a.Krow : (size_t)a.Krow);
 #pragma unroll
     for (int n1 = 0; n1 < P; ++n1) {
       const int n = G::N2 * n1 + tseq;
       const int tap = n / a.dil;
       const bool hit = (tap * a.dil == n) && tap < a.K;
-      const int ts = a.transposed ? a.K - 1 - tap : tap;
+      const int ts = a.transposed ? a.Krow - 1 - (a.k0 + tap) : a.k0 + tap;
       v[n1].x = (hit && has0) ? w0[ts] : 0.f;
       v[n1].y = (hit && has1) ? w1[ts] : 0.f;
     }

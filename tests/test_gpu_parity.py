@@ -460,3 +460,36 @@ def test_depthwise_blocks(case):
     for a_, b_ in ((got, want), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
         err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
         assert err < REL_TOL, (case, err)
+
+
+LONG_KERNEL_CASES = [  # B, Cin, Cout, groups, L, K, padding, dilation, mode
+    (2, 8, 8, 1, 20000, 5000, 0, 1, "constant"),          # batch-sharing kernel, 5 segments
+    (3, 4, 6, 1, 12000, 3000, 50, 2, "reflect"),          # general kernel, dilated extent 5999
+    (2, 16, 16, 16, 9000, 2048, 0, 1, "constant"),        # depthwise blocks, 2 segments
+    (2, 12, 8, 1, 15000, 4500, 100, 1, "circular"),       # two input chunks + segments
+    (1, 8, 8, 1, 8192, 8192, 4096, 1, "constant"),        # kernel as long as the row
+]
+
+
+@pytest.mark.parametrize("case", LONG_KERNEL_CASES)
+def test_long_kernels_run_in_segments(case):
+    """Kernels longer than the largest FFT tile (and 8-channel shapes beyond 1537 taps) run as segments of taps
+    that accumulate into y; forward and all three gradients against torch's direct convolution in float64."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    B, cin, cout, groups, L, K, pad, dil, mode = case
+    gen = torch.Generator().manual_seed(333 + K)
+    x = torch.randn(B, cin, L, generator=gen, dtype=torch.float64)
+    w = torch.randn(cout, cin // groups, K, generator=gen, dtype=torch.float64) / (K * cin // groups) ** 0.5
+    b = torch.randn(cout, generator=gen, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    xp = F.pad(xr, [pad, pad], mode=mode) if (mode != "constant" and pad) else xr
+    want = F.conv1d(xp, wr, br, padding=pad if mode == "constant" else 0, dilation=dil, groups=groups)
+    xd, wd, bd = (t.float().to(DEV).requires_grad_() for t in (x, w, b))
+    got = fft_conv(xd, wd, bias=bd, padding=pad, dilation=dil, groups=groups, padding_mode=mode)
+    assert got.shape == want.shape
+    gy = torch.randn(want.shape, generator=gen, dtype=torch.float64)
+    want.backward(gy)
+    got.backward(gy.float().to(DEV))
+    for name, a_, b_ in (("y", got, want), ("dX", xd.grad, xr.grad), ("dW", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
+        assert err < REL_TOL, (case, name, err)

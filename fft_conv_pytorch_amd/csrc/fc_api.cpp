@@ -629,7 +629,10 @@ int fc_plan_tile(const fc_plan* plan) { return plan && plan->tile ? plan->tile->
 
 // ---- 1-D weight gradient
 namespace {
-struct WgradGeom { const fc::TileImpl* t; int kd, V, ntiles, nob, nib, Cig, Cog, n_items, ipw, slices, pad; };
+struct WgradGeom {
+  const fc::TileImpl* t;
+  int kd_seg, seg_taps, nseg, V, ntiles, nob, nib, Cig, Cog, n_items, ipw, slices, pad, diag;
+};
 int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   if (d.ndim != 1 || d.dtype != FC_F32 || d.transposed || d.stride[0] != 1 || d.groups < 1) return 0;
   if (d.batch < 1 || d.in_channels % d.groups || d.out_channels % d.groups) return 0;
@@ -637,22 +640,31 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   if (Cig > 64 || Cog > 64) return 0;      // every 4 x 4 channel block repeats the transforms of its rows: beyond this the plan path wins
   const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
   const fc::TileImpl* t = find_tile(1024);
-  if (!t || !t->wgrad1d || kd > 768 || d.padding[0] < 0) return 0;
+  if (!t || !t->wgrad1d || d.padding[0] < 0 || d.dilation[0] > 512) return 0;
   const int64_t Lout = d.spatial[0] + 2 * d.padding[0] - kd + 1;
   if (Lout < 1) return 0;
   if (d.padding_mode == FC_PAD_REFLECT && d.padding[0] >= d.spatial[0]) return 0;
   if (d.padding_mode == FC_PAD_CIRCULAR && d.padding[0] > d.spatial[0]) return 0;
   if ((int64_t)d.batch * d.in_channels * d.spatial[0] * 4 >= ((int64_t)1 << 32) ||
       (int64_t)d.batch * d.out_channels * Lout * 4 >= ((int64_t)1 << 32)) return 0;
-  const int64_t V = t->T - kd + 1, ntiles = (Lout + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
+  // the lags of one launch fit half a tile; longer kernels run in segments of taps (x read further in)
+  const int64_t ks = std::min<int64_t>(d.kernel[0], kd <= 768 ? d.kernel[0] : 512 / d.dilation[0] + 1);
+  const int64_t kd_seg = (ks - 1) * d.dilation[0] + 1;
+  const int64_t nseg = (d.kernel[0] + ks - 1) / ks;
+  if (nseg > 64) return 0;
+  const int64_t V = t->T - kd_seg + 1, ntiles = (Lout + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
   if (n_items > 0x3fffffff) return 0;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  const int nb = t->wgrad_nb;
-  g->t = t; g->kd = (int)kd; g->V = (int)V; g->ntiles = (int)ntiles; g->Cig = (int)Cig; g->Cog = (int)Cog;
+  const char* env = getenv("FFTCONV_DIAG");
+  g->diag = (!env || atoi(env) != 0) && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 &&
+            t->wgrad1d_diag != nullptr;
+  const int nb = g->diag ? 1 : t->wgrad_nb;
+  g->t = t; g->kd_seg = (int)kd_seg; g->seg_taps = (int)ks; g->nseg = (int)nseg; g->V = (int)V; g->ntiles = (int)ntiles;
+  g->Cig = (int)Cig; g->Cog = (int)Cog;
   g->nob = (int)(Cog + 3) / 4; g->nib = (int)(Cig + 3) / 4; g->n_items = (int)n_items; g->pad = (int)d.padding[0];
-  const int64_t types = (int64_t)d.groups * g->nob * g->nib;
+  const int64_t types = g->diag ? d.groups / 8 : (int64_t)d.groups * g->nob * g->nib;
   // two workgroups per CU; every slice costs one inverse transform and one partial result, so a slice
   // gets at least 4 iterations of work
   int64_t slices = std::max<int64_t>(1, (2 * (int64_t)cus + types - 1) / types);
@@ -682,15 +694,24 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
   const fc_desc& d = *desc;
   fc::WGradArgs a;
   a.x = x; a.dy = dy; a.part = partial; a.twA = tw.twA; a.twB = tw.twB;
-  a.B = (int)d.batch; a.Cin = (int)d.in_channels; a.Cout = (int)d.out_channels; a.G = (int)d.groups;
+  a.B = (int)d.batch; a.Cin = (int)d.in_channels; a.Cout = (int)d.out_channels;
+  a.G = g.diag ? (int)(d.groups / 8) : (int)d.groups;
   a.Cig = g.Cig; a.Cog = g.Cog; a.L = (int)d.spatial[0]; a.pad = g.pad; a.pad_mode = d.padding_mode;
-  a.Lout = (int)(d.spatial[0] + 2 * d.padding[0] - g.kd + 1);
-  a.K = (int)d.kernel[0]; a.dil = (int)d.dilation[0]; a.V = g.V; a.ntiles = g.ntiles;
+  const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
+  a.Lout = (int)(d.spatial[0] + 2 * d.padding[0] - kd + 1);
+  a.dil = (int)d.dilation[0]; a.V = g.V; a.ntiles = g.ntiles;
   a.n_items = g.n_items; a.items_per_slice = g.ipw; a.nob = g.nob; a.nib = g.nib;
   a.scale = 1.0f / (4.0f * (float)g.t->T);
-  const int64_t grid = (int64_t)g.slices * d.groups * g.nob * g.nib;
+  a.Krow = (int)d.kernel[0];
+  const int64_t grid = g.diag ? (int64_t)g.slices * (d.groups / 8) : (int64_t)g.slices * d.groups * g.nob * g.nib;
   if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
-  FC_HIP(g.t->wgrad1d(a, (int)grid, (hipStream_t)hip_stream));
+  for (int j = 0; j < g.nseg; ++j) {
+    a.tap0 = j * g.seg_taps;
+    a.K = std::min(g.seg_taps, (int)d.kernel[0] - a.tap0);
+    a.pos_shift = a.tap0 * (int)d.dilation[0];
+    if (g.diag) FC_HIP(g.t->wgrad1d_diag(a, (int)grid, (hipStream_t)hip_stream));
+    else FC_HIP(g.t->wgrad1d(a, (int)grid, (hipStream_t)hip_stream));
+  }
   return FC_OK;
 }
 

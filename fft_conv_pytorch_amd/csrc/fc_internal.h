@@ -35,6 +35,7 @@ struct TileImpl {
   size_t wide_lds;
   // 1-D weight gradient (wgrad1d.hpp), built for the 1024-point tile only (else null)
   hipError_t (*wgrad1d)(const WGradArgs& a, int grid, hipStream_t st);
+  hipError_t (*wgrad1d_diag)(const WGradArgs& a, int grid, hipStream_t st);   // depthwise blocks of 8 channels
   int wgrad_nb;          // items per iteration of that kernel
 };
 

@@ -234,6 +234,16 @@ hipError_t wgrad_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
   return hipGetLastError();
 }
+hipError_t wgrad_diag_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
+  constexpr int NT = 8 * GG::TS;
+  auto k = wgrad1d_diag_kernel<FC_P, FC_S, NT>;
+  const size_t lds = ((size_t)FC_P * GG::N2 + (size_t)8 * GG::LSEQ) * sizeof(float2);
+  static bool done = false;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
+  return hipGetLastError();
+}
 #else
 constexpr int kWgradNb = 0;
 #endif
@@ -251,9 +261,9 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
                                 {kPersNb0 * 4 * GG::TS, kPersNb1 * 4 * GG::TS},
                                 wide_dispatch, kWideNb, kWideNb ? pers_lds_bytes(kWideNb) : 0,
 #if FC_P == 32 && FC_S == 1
-                                wgrad_dispatch,
+                                wgrad_dispatch, wgrad_diag_dispatch,
 #else
-                                nullptr,
+                                nullptr, nullptr,
 #endif
                                 kWgradNb};
   return &impl;

@@ -26,7 +26,9 @@ struct WGradArgs {
   const f2* twB;
   int B, Cin, Cout, G, Cig, Cog;
   int L, pad, pad_mode, Lout;
-  int K, dil, V, ntiles;           // taps, dilation, dY samples per tile, tiles per row
+  int K, dil, V, ntiles;           // taps of THIS segment, dilation, dY samples per tile, tiles per row
+  int Krow, tap0;                  // taps per weight row, first tap of this segment (kernels longer than one
+  int pos_shift;                   //   tile's lag window run in segments: x is read tap0*dil samples further in)
   int n_items, items_per_slice;    // (b, tile) items in all / per slice (a multiple of NB)
   int nob, nib;                    // 4-channel blocks per group: outputs, inputs
   float scale;                     // 1 / (4 T)
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
         const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;
         const unsigned ro0 = ((unsigned)b * (unsigned)a.Cin + (unsigned)(g * a.Cig + ci0)) * (unsigned)a.L * 4u;
         const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
-        const int tile_pos = tile * a.V - a.pad;
+        const int tile_pos = tile * a.V - a.pad + a.pos_shift;
         if (tile_pos >= 0 && tile_pos + T <= a.L && has1) {
           const unsigned v0 = ro0 + (unsigned)(tile_pos + tseq) * 4u, v1 = ro1 + (unsigned)(tile_pos + tseq) * 4u;
 #pragma unroll
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
       const int o = pk >> 1, ip = pk & 1;
       const int co = ob * 4 + o, ci = ib * 4 + 2 * ip;
       if (co < a.Cog) {
-        float* out0 = a.part + (((size_t)slice * a.Cout + (co_base + o)) * a.Cig + ci) * a.K;
-        float* out1 = out0 + a.K;
+        float* out0 = a.part + (((size_t)slice * a.Cout + (co_base + o)) * a.Cig + ci) * a.Krow + a.tap0;
+        float* out1 = out0 + a.Krow;
         const int nbase = (tseq >> G::LGS) + P * P * j;
         const int kd = (a.K - 1) * a.dil + 1;
 #pragma unroll
@@ -248,6 +250,173 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
     __syncthreads();
   }
   (void)ci_base;
+}
+
+// Depthwise variant (groups == Cin == Cout, a multiple of 8): a workgroup owns the 8 channels of block g
+// and a slice of the items; per item it transforms 4 input pairs + 4 gradient pairs and accumulates ONE
+// cross-spectrum per channel (8 per bin pair).  part is [slices][C][1][Krow].
+template <int P, int S, int NT>
+__global__ __launch_bounds__(NT, 2) void wgrad1d_diag_kernel(const WGradArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T;
+  constexpr int NSEQ = 8;
+  static_assert(NT == NSEQ * G::TS, "one thread slot per point group of every sequence");
+  static_assert(G::TS <= 64 && (4 * G::TS) % 64 == 0, "the sequences of one role are a whole number of wavefronts");
+  static_assert((T / 2) % NT == 0, "bin pairs divide evenly over the threads");
+  constexpr int BP = (T / 2) / NT;
+  constexpr int TWN = P * G::N2;
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  f2* twl = lds;
+  f2* zbuf = lds + TWN;                     // [8][LSEQ]: X pairs 0..3, dY pairs 0..3
+
+  const int tid = threadIdx.x;
+  const int sq = tid / G::TS, tseq = tid % G::TS;
+  const int role = __builtin_amdgcn_readfirstlane(sq >> 2);              // 0: input pair, 1: gradient pair
+  const int pr = sq & 3;
+  f2* zseq = zbuf + sq * G::LSEQ;
+  const int g = blockIdx.x % a.G;           // channel block
+  const int slice = blockIdx.x / a.G;
+  const int item_lo = slice * a.items_per_slice;
+  const int item_hi = min(item_lo + a.items_per_slice, a.n_items);
+  const int c0 = g * 8 + 2 * pr;            // this sequence's two channels
+
+  const PadMap pm = make_padmap(a.pad_mode, a.L);
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const BufRsrc xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.Cin * a.L * 4));
+  const BufRsrc yr = make_rsrc(a.dy, (unsigned)((size_t)a.B * a.Cout * a.Lout * 4));
+  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+
+  f2 acc[BP][4][2];                          // [bin pair][channel pair][even / odd channel]
+#pragma unroll
+  for (int m = 0; m < BP; ++m)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { acc[m][p][0] = mk2(0.f, 0.f); acc[m][p][1] = mk2(0.f, 0.f); }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int item = item_lo; item < item_hi; ++item) {
+    const int b = item / a.ntiles, tile = item - b * a.ntiles;
+    {
+      f2 v[P];
+      if (role == 0) {
+        const unsigned ro0 = ((unsigned)b * (unsigned)a.Cin + (unsigned)c0) * (unsigned)a.L * 4u;
+        const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
+        const int tile_pos = tile * a.V - a.pad + a.pos_shift;
+        if (tile_pos >= 0 && tile_pos + T <= a.L) {
+          const unsigned v0 = ro0 + (unsigned)(tile_pos + tseq) * 4u, v1 = ro1 + (unsigned)(tile_pos + tseq) * 4u;
+#pragma unroll
+          for (int n1 = 0; n1 < P; ++n1) {
+            v[n1].x = buf_load_f32(xr, v0, G::N2 * n1 * 4);
+            v[n1].y = buf_load_f32(xr, v1, G::N2 * n1 * 4);
+          }
+        } else {
+#pragma unroll
+          for (int n1 = 0; n1 < P; ++n1) {
+            const int pos = tile_pos + G::N2 * n1 + tseq;
+            v[n1].x = buf_load_f32(xr, padded_offset(ro0, pos, a.L, a.pad, pm, true), 0);
+            v[n1].y = buf_load_f32(xr, padded_offset(ro1, pos, a.L, a.pad, pm, true), 0);
+          }
+        }
+      } else {
+        const unsigned ro0 = ((unsigned)b * (unsigned)a.Cout + (unsigned)c0) * (unsigned)a.Lout * 4u;
+        const unsigned ro1 = ro0 + (unsigned)a.Lout * 4u;
+        const int t0 = tile * a.V;
+        const int limit = min(a.V, a.Lout - t0);
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int n = G::N2 * n1 + tseq;
+          const bool in = n < limit;
+          v[n1].x = buf_load_f32(yr, in ? ro0 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+          v[n1].y = buf_load_f32(yr, in ? ro1 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+        }
+      }
+      passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
+      seq_sync<G>();
+      passB_load<G>(v, zseq, tseq);
+      seq_sync<G>();
+      const int j = passB_compute<G, -1>(v, tseq, twB);
+      const int k1 = tseq >> G::LGS;
+      f2* dst = zseq + G::nat(k1 + P * P * j);
+#pragma unroll
+      for (int k = 0; k < P; ++k) dst[P * k] = v[k];
+    }
+    __syncthreads();
+    static_for<0, BP>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      const int f = tid + m * NT;
+      const int fm = (T - f) & (T - 1);
+      const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
+      f2 zf[8], zg[8];
+      static_for<0, 8>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        zf[q] = lds_rd_far<q * G::LSEQ * 8>(af);
+        zg[q] = lds_rd_far<q * G::LSEQ * 8>(ag);
+      });
+      lds_arrive(zf);
+      lds_arrive(zg);
+      if (f != 0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          cmacc(acc[m][p][0], add_conj(zf[4 + p], zg[4 + p]), add_conj(zf[p], zg[p]));
+          cmacc(acc[m][p][1], sub_conj_divi(zf[4 + p], zg[4 + p]), sub_conj_divi(zf[p], zg[p]));
+        }
+      } else {
+        // bins 0 and T/2 are real: accumulate them as one (bin 0, bin T/2) pair per channel
+        const unsigned ah = lds_off(zbuf + G::nat(T / 2));
+        f2 zh[8];
+        static_for<0, 8>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          zh[q] = lds_rd_far<q * G::LSEQ * 8>(ah);
+        });
+        lds_arrive(zh);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          acc[m][p][0] = pkfma(mk2(2.f * zf[4 + p].x, 2.f * zh[4 + p].x), mk2(2.f * zf[p].x, 2.f * zh[p].x), acc[m][p][0]);
+          acc[m][p][1] = pkfma(mk2(2.f * zf[4 + p].y, 2.f * zh[4 + p].y), mk2(2.f * zf[p].y, 2.f * zh[p].y), acc[m][p][1]);
+        }
+      }
+    });
+    __syncthreads();
+  }
+
+  // -------------------------------------------------- 8 cross-spectra = 4 packed sequences -> inverse -> taps
+#pragma unroll
+  for (int m = 0; m < BP; ++m) {
+    const int f = tid + m * NT;
+    const int fm = (T - f) & (T - 1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const f2 A = acc[m][p][0], Bv = acc[m][p][1];
+      f2* zb = zbuf + p * G::LSEQ;
+      if (f != 0) {
+        zb[G::nat(f)] = add_pi(A, Bv);
+        zb[G::nat(fm)] = conj_add_iconj(A, Bv);
+      } else {
+        zb[G::nat(0)] = mk2(A.x, Bv.x);
+        zb[G::nat(T / 2)] = mk2(A.y, Bv.y);
+      }
+    }
+  }
+  __syncthreads();
+  if (sq < 4) {
+    f2 v[P];
+    nat_load<G>(v, zseq, tseq);
+    seq_sync<G>();
+    passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
+    seq_sync<G>();
+    passB_load<G>(v, zseq, tseq);
+    const int j = passB_compute<G, +1>(v, tseq, twB);
+    float* out0 = a.part + ((size_t)slice * a.Cout + c0) * a.Krow + a.tap0;
+    float* out1 = out0 + a.Krow;
+    const int nbase = (tseq >> G::LGS) + P * P * j;
+    const int kd = (a.K - 1) * a.dil + 1;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const int lag = nbase + P * k;
+      const int tap = lag / a.dil;
+      if (lag < kd && tap * a.dil == lag) { out0[tap] = v[k].x * a.scale; out1[tap] = v[k].y * a.scale; }
+    }
+  }
 }
 
 }  // namespace fc

@@ -301,7 +301,7 @@ WGRAD_CASES = [  # B, Cin, Cout, groups, L, K, padding, dilation, mode
     (1, 8, 8, 1, 700, 33, 0, 3, "constant"),          # single tile, dilation 3
     (5, 16, 24, 4, 5000, 129, 64, 2, "reflect"),      # groups, 4 in / 6 out per group
     (2, 6, 6, 2, 4096, 1, 0, 1, "constant"),          # 1-tap kernel
-    (7, 8, 8, 1, 3000, 385, 100, 2, "circular"),      # dilated extent 769 > 768: falls back to the plan path
+    (7, 8, 8, 1, 3000, 385, 100, 2, "circular"),      # dilated extent 769: two segments of taps
     (4, 7, 8, 1, 1500, 200, 30, 1, "replicate"),
     (9, 8, 8, 8, 10000, 65, 5, 1, "constant"),        # depthwise-like: one channel per group
     (2, 24, 40, 1, 3000, 65, 0, 1, "constant"),       # 6 x 10 blocks of 4 x 4 channels
@@ -310,8 +310,8 @@ WGRAD_CASES = [  # B, Cin, Cout, groups, L, K, padding, dilation, mode
 
 @pytest.mark.parametrize("case", WGRAD_CASES)
 def test_weight_gradient_kernel(case):
-    """fc_wgrad1d (cross-spectra accumulated on chip) against autograd through torch's direct convolution in
-    float64; shapes it does not cover must come back through the plan-based path with the same result."""
+    """fc_wgrad1d (cross-spectra accumulated on chip; long kernels in segments of taps) against autograd through
+    torch's direct convolution in float64."""
     from fft_conv_pytorch_amd import autograd as ag
     B, cin, cout, groups, L, K, pad, dil, mode = case
     gen = torch.Generator().manual_seed(1234 + L)
@@ -323,7 +323,7 @@ def test_weight_gradient_kernel(case):
     (want,) = torch.autograd.grad(y, w, gy)
     got = ag._grad_weight(x.to(DEV), gy.float().to(DEV), tuple(w.shape), (1,), (pad,), (dil,), groups, mode)
     covered = ag._grad_weight_native(x.to(DEV), gy.float().to(DEV), tuple(w.shape), (1,), (pad,), (dil,), groups, mode)
-    assert (covered is None) == ((K - 1) * dil + 1 > 768)
+    assert covered is not None
     assert got.shape == want.shape
     err = (got.double().cpu() - want).norm().item() / want.norm().item()
     print(f"wgrad {case}: rel err {err:.2e}")

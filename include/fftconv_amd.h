@@ -98,7 +98,8 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
  *   dW[o][i][k] = sum_b sum_t dY[b][o][t] * pad(x)[b][i][t + k*dilation]
  * i.e. what autograd derives from functional.py:60-87 for `kernel` (pinned by the reference's
  * tests/test_functional.py:111-117).  Covered: ndim 1, stride 1, <= 64 channels per group on both
- * sides, dilated kernel extent <= 768, any padding mode.  Cross-spectra are accumulated over the batch
+ * sides, any kernel length and padding mode (long kernels run in segments of taps; depthwise shapes
+ * with a multiple of 8 channels take a per-channel variant).  Cross-spectra are accumulated over the batch
  * and the row on chip; the result comes in `slices` partial tensors that the caller sums:
  *   partial is (slices, Cout, Cin/groups, K) fp32, fully written by the call.
  * fc_wgrad1d_slices returns the slice count for the current device, 0 when the shape is not covered

@@ -129,6 +129,7 @@ struct fc_plan {
   int64_t kd_plan;            // dilated extent the tiles are planned for (of one segment)
   size_t seg_spectrum_bytes;  // kernel-spectrum bytes of one segment
   int diag;                   // depthwise (groups == Cin == Cout, multiple of 8): 8-channel blocks, per-channel mix
+  int bd_gs;                  // groups of 2 or 4 channels regrouped into block-diagonal 8 x 8 blocks (0 = off)
   int G;                      // channel groups as the 1-D kernels see them (C/8 blocks for a depthwise plan)
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
@@ -166,6 +167,22 @@ static int plan_1d(fc_plan* p) {
   const char* env = getenv("FFTCONV_DIAG");
   const bool want = !env || atoi(env) != 0;
   p->diag = 0;
+  p->bd_gs = 0;
+  {
+    // groups of 2 or 4 channels (in == out per group): 8 / gs of them form one dense 8 x 8 block whose
+    // cross-group spectrum entries are zero -- the batch-sharing kernel runs it as is
+    const int64_t gs = d.in_channels / d.groups;
+    if (want && (gs == 2 || gs == 4) && d.out_channels / d.groups == gs && d.groups % (8 / gs) == 0 && d.stride[0] == 1 &&
+        !(d.tile_hint && !getenv("FFTCONV_PERS"))) {
+      p->bd_gs = (int)gs;
+      set_channel_layout(p, (int)(d.groups * gs / 8), 8, 8);
+      const int rc = plan_1d_inner(p);
+      if (rc == FC_OK && p->pers_nb != 0) return FC_OK;
+      if (p->d_items) { (void)hipFree(p->d_items); p->d_items = nullptr; }
+      p->bd_gs = 0;
+      set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
+    }
+  }
   if (want && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 && d.stride[0] == 1 &&
       !(d.tile_hint && !getenv("FFTCONV_PERS"))) {
     p->diag = 1;
@@ -746,6 +763,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     if (p.diag) {   // depthwise: (C, 1, K) read as one output row over C inputs -> [C/2 pairs][T/2] float4
       a.G = 1; a.Cog = 1; a.Cog_pad = 1; a.Cig = (int)p.d.in_channels; a.Cig_pad = a.Cig;
     }
+    a.gs = p.bd_gs;
     a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
     a.transposed = p.d.transposed;

@@ -19,6 +19,8 @@ struct Spec1dArgs {
   const f2* twA;
   const f2* twB;
   int G, Cig, Cog, Cig_pad, Cog_pad, K, dil, nseq;
+  int gs;              // > 0: the 8 x 8 blocks are block-diagonal, built from groups of gs channels (2 or 4) of a
+                       // (C, gs, K) weight tensor; entries that cross a group stay zero
   int Krow, k0;        // taps per weight row and first tap of this kernel segment (K = taps of the segment)
   int transposed;      // kernel is (Cin, Cout/g, K): swap in/out inside the group and flip the taps
 };
@@ -43,11 +45,22 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
   const int g = act ? seq / (npi * a.Cog_pad) : 0;
   {
     f2 v[P];
-    const bool has0 = act && o < a.Cog && 2 * ip < a.Cig;
-    const bool has1 = act && o < a.Cog && 2 * ip + 1 < a.Cig;
+    bool has0 = act && o < a.Cog && 2 * ip < a.Cig;
+    bool has1 = act && o < a.Cog && 2 * ip + 1 < a.Cig;
     const float* w0 = a.transposed ? a.w + ((size_t)(g * a.Cig + 2 * ip) * a.Cog + o) * a.Krow
                                    : a.w + ((size_t)(g * a.Cog + o) * a.Cig + 2 * ip) * a.Krow;
     const float* w1 = w0 + (a.transposed ? (size_t)a.Cog * a.Krow : (size_t)a.Krow);
+    if (a.gs > 0) {
+      // block g holds 8 / gs original groups; (o, input pair ip) is live only inside one of them
+      const int gl = o / a.gs, ol = o % a.gs, il = (2 * ip) % a.gs;
+      const bool same = (2 * ip) / a.gs == gl;
+      has0 = has0 && same; has1 = has1 && same;
+      const size_t grp = (size_t)g * (8 / a.gs) + gl;                  // original group
+      w0 = a.transposed ? a.w + ((grp * a.gs + il) * a.gs + ol) * a.Krow     // (Cin, gs, K): [input][output in group]
+                        : a.w + ((grp * a.gs + ol) * a.gs + il) * a.Krow;    // (Cout, gs, K): [output][input in group]
+      w1 = w0 + (a.transposed ? (size_t)a.gs * a.Krow : (size_t)a.Krow);
+      if (!same) { w0 = a.w; w1 = a.w; }
+    }
 #pragma unroll
     for (int n1 = 0; n1 < P; ++n1) {
       const int n = G::N2 * n1 + tseq;

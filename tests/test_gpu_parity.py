@@ -493,3 +493,36 @@ def test_long_kernels_run_in_segments(case):
     for name, a_, b_ in (("y", got, want), ("dX", xd.grad, xr.grad), ("dW", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
         err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
         assert err < REL_TOL, (case, name, err)
+
+
+SMALL_GROUP_CASES = [  # B, C, group size, L, K, padding, dilation, mode
+    (4, 16, 2, 20000, 257, 0, 1, "constant"),
+    (3, 32, 4, 9000, 129, 30, 1, "reflect"),
+    (5, 8, 4, 5000, 513, 0, 2, "constant"),
+    (2, 24, 2, 3000, 65, 10, 1, "circular"),
+    (2, 12, 4, 3000, 65, 0, 1, "constant"),        # 3 groups of 4: not a whole number of 8-channel blocks -> generic plan
+]
+
+
+@pytest.mark.parametrize("case", SMALL_GROUP_CASES)
+def test_small_groups_as_block_diagonal_blocks(case):
+    """Groups of 2 or 4 channels are regrouped into 8 x 8 blocks with a block-diagonal spectrum and run on the
+    batch-sharing kernel; forward and gradients against torch's direct convolution in float64."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    B, C, gs, L, K, pad, dil, mode = case
+    groups = C // gs
+    gen = torch.Generator().manual_seed(77 + C + K)
+    x = torch.randn(B, C, L, generator=gen, dtype=torch.float64)
+    w = torch.randn(C, gs, K, generator=gen, dtype=torch.float64) / (K * gs) ** 0.5
+    b = torch.randn(C, generator=gen, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    xp = F.pad(xr, [pad, pad], mode=mode) if (mode != "constant" and pad) else xr
+    want = F.conv1d(xp, wr, br, padding=pad if mode == "constant" else 0, dilation=dil, groups=groups)
+    xd, wd, bd = (t.float().to(DEV).requires_grad_() for t in (x, w, b))
+    got = fft_conv(xd, wd, bias=bd, padding=pad, dilation=dil, groups=groups, padding_mode=mode)
+    gy = torch.randn(want.shape, generator=gen, dtype=torch.float64)
+    want.backward(gy)
+    got.backward(gy.float().to(DEV))
+    for name, a_, b_ in (("y", got, want), ("dX", xd.grad, xr.grad), ("dW", wd.grad, wr.grad), ("db", bd.grad, br.grad)):
+        err = (a_.detach().double().cpu() - b_.detach()).norm().item() / b_.detach().norm().item()
+        assert err < REL_TOL, (case, name, err)

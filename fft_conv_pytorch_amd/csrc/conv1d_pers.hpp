@@ -81,7 +81,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const float* xbase = a.x + ((size_t)bfirst * a.Cin + (size_t)g * a.Cig) * a.L;
     const BufRsrc xg = make_rsrc(xbase, (unsigned)(((size_t)(blast - bfirst) * a.Cin + a.Cig) * a.L * 4));
     const int ci0 = 2 * pr;
-    const bool has0 = act_in && ci0 < a.Cig, has1 = act_in && ci0 + 1 < a.Cig;
+    // (a depthwise plan's last block may reach past the last channel)
+    const bool has0 = act_in && ci0 < a.Cig && (!DIAG || g * CIB + ci0 < a.Cin);
+    const bool has1 = act_in && ci0 + 1 < a.Cig && (!DIAG || g * CIB + ci0 + 1 < a.Cin);
     const unsigned ro0 = ((unsigned)(b - bfirst) * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
     const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
     if (interior && has1 && !PHASES) {
@@ -119,8 +121,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     stamp_item(a.stamps, it, 0);
     // bias of this lane's two output channels, requested now and used in the last pass
     const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
-    const float bias0 = a.bias ? a.bias[cg0] : 0.f;
-    const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
+    const bool ok0 = !DIAG || cg0 < a.Cout, ok1 = !DIAG || cg0 + 1 < a.Cout;
+    const float bias0 = (a.bias && ok0) ? a.bias[cg0] : 0.f;
+    const float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
     // ------------------------------------------------ forward pass A
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
     // (act_in is wave-uniform and the two passes of a sequence only need wave-level ordering)
@@ -323,7 +326,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       const int nbase = o1 + P * P * j;
       float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase) * nph + phase;
       float* y1 = y0 + a.Lout;
-      if (SEG && a.add_out) {
+      if constexpr (DIAG) {
+        // depthwise: the last block may hold fewer than 8 channels, so every row is guarded
+        const int ystep = P * nph;
+        const bool addo = SEG && a.add_out;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+          if (nbase + P * k < limit) {
+            if (ok0) y0[ystep * k] = v[k].x + (addo ? y0[ystep * k] : bias0);
+            if (ok1) y1[ystep * k] = v[k].y + (addo ? y1[ystep * k] : bias1);
+          }
+      } else if (SEG && a.add_out) {
         // later segments of a long kernel accumulate into the output of the first
         const int ystep = P * nph;
 #pragma unroll

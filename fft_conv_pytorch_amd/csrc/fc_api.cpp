@@ -160,7 +160,7 @@ static void set_channel_layout(fc_plan* p, int G, int Cig, int Cog) {
 
 static int plan_1d_inner(fc_plan* p);
 
-// Depthwise rows (groups == Cin == Cout, a multiple of 8, stride 1) run on the batch-sharing kernel as blocks of
+// Depthwise rows (groups == Cin == Cout >= 5, stride 1) run on the batch-sharing kernel as blocks of
 // 8 channels with a per-channel mix; when that kernel cannot take the shape the generic grouped plan is used.
 static int plan_1d(fc_plan* p) {
   const fc_desc& d = p->d;
@@ -183,10 +183,10 @@ static int plan_1d(fc_plan* p) {
       set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
     }
   }
-  if (want && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 && d.stride[0] == 1 &&
+  if (want && d.groups == d.in_channels && d.groups == d.out_channels && d.groups >= 5 && d.stride[0] == 1 &&
       !(d.tile_hint && !getenv("FFTCONV_PERS"))) {
-    p->diag = 1;
-    set_channel_layout(p, (int)(d.groups / 8), 8, 8);
+    p->diag = 1;                                       // (the last block may be partly empty: the kernel masks it)
+    set_channel_layout(p, (int)((d.groups + 7) / 8), 8, 8);
     const int rc = plan_1d_inner(p);
     if (rc == FC_OK && p->pers_nb != 0) return FC_OK;
     if (p->d_items) { (void)hipFree(p->d_items); p->d_items = nullptr; }
@@ -297,7 +297,7 @@ static int plan_1d_inner(fc_plan* p) {
   const size_t per_group = (size_t)p->Cog_pad * (p->Cig_pad / 2) * (best->T / 2) * sizeof(fc::f4);
   if (per_group >= ((size_t)1 << 32))
     return fail(FC_ERR_UNSUPPORTED, "kernel spectrum of one group exceeds 4 GiB");
-  p->seg_spectrum_bytes = p->diag ? (size_t)(d.in_channels / 2) * (best->T / 2) * sizeof(fc::f4) : per_group * (size_t)p->G;
+  p->seg_spectrum_bytes = p->diag ? (size_t)(round_up(d.in_channels, 8) / 2) * (best->T / 2) * sizeof(fc::f4) : per_group * (size_t)p->G;
   p->spectrum_bytes = p->seg_spectrum_bytes * (size_t)p->nseg;
   p->workspace_bytes = 0;
   int rc = get_twiddles(best, &p->tw);
@@ -761,7 +761,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.twB = p.tw.twB;
     a.G = p.G; a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad;
     if (p.diag) {   // depthwise: (C, 1, K) read as one output row over C inputs -> [C/2 pairs][T/2] float4
-      a.G = 1; a.Cog = 1; a.Cog_pad = 1; a.Cig = (int)p.d.in_channels; a.Cig_pad = a.Cig;
+      a.G = 1; a.Cog = 1; a.Cog_pad = 1; a.Cig = (int)p.d.in_channels; a.Cig_pad = (int)round_up(p.d.in_channels, 8);
     }
     a.gs = p.bd_gs;
     a.dil = p.ph > 1 ? 1 : (int)p.d.dilation[0];

@@ -435,7 +435,9 @@ DEPTHWISE_CASES = [  # B, C, L, K, padding, dilation, mode
     (1, 8, 100000, 257, 0, 1, "constant"),       # batch 1: tile slots
     (5, 16, 9000, 129, 64, 3, "circular"),       # dilation as phases on depthwise blocks
     (2, 40, 3000, 700, 10, 1, "replicate"),
-    (4, 12, 2000, 65, 0, 1, "constant"),         # 12 channels: not a multiple of 8 -> generic grouped plan
+    (4, 12, 2000, 65, 0, 1, "constant"),         # 12 channels: the second block is half empty
+    (3, 5, 3000, 129, 7, 1, "reflect"),          # one block, 5 of 8 channels (odd count: a lone channel in a pair)
+    (2, 21, 2500, 300, 0, 2, "constant"),        # 21 channels, dilation phases
 ]
 
 

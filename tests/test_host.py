@@ -93,3 +93,13 @@ def test_wgrad_descriptor_query_is_safe_without_a_device():
     assert (_native.wgrad1d_slices(ok) > 0) == has_gpu
     assert _native.wgrad1d_slices(strided) == 0
     assert _native.wgrad1d_slices(two_d) == 0
+
+
+def test_scripts_and_entry_points_compile():
+    """Helper scripts are not exercised by the suite; at least keep them syntactically valid."""
+    import py_compile
+    for name in sorted(os.listdir(os.path.join(ROOT, "scripts"))):
+        if name.endswith(".py"):
+            py_compile.compile(os.path.join(ROOT, "scripts", name), doraise=True)
+    for name in ("bench.py", "__graft_entry__.py"):
+        py_compile.compile(os.path.join(ROOT, name), doraise=True)

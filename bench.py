@@ -137,6 +137,8 @@ def main():
     if world > 1:   # every rank holds the same parameters (as after loading one checkpoint)
         dist.broadcast(layer.weight.data, src=0)
         dist.broadcast(layer.bias.data, src=0)
+        layer.invalidate_kernel_spectrum()       # .data writes bypass the version counter the cache keys on
+    layer.eval()                                  # inference: the module reuses the kernel spectrum per weight version
 
     # distinct buffer sets, > 2x the Infinity Cache in total
     in_bytes = 4 * batch * cin
@@ -151,7 +153,7 @@ def main():
     ys = [torch.empty_like(y0) for _ in range(nbuf)]
     alg_bytes, n_out = algorithmic_bytes(batch, cin, cout, groups, spatial, kernel, out_spatial)
 
-    spectrum = layer.__dict__["_spectrum_cache"][1]
+    spectrum = layer.__dict__["_spectrum_cache"][1]     # what the module's own forward uses
     plan = spectrum.plan
     if world > 1:
         # the path's only exchange: rank 0 transforms the kernel, RCCL broadcasts the spectrum over xGMI
@@ -159,11 +161,13 @@ def main():
         spectrum = broadcast_kernel_spectrum(plan, layer.weight.detach(), src=0)
     bias_ptr = layer.bias.data_ptr()
     stream = torch.cuda.current_stream(dev)
+    from fft_conv_pytorch_amd.functional import new_workspace
+    workspace = new_workspace(plan, dev)      # N-d plans only; the steps run one after another on one stream
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
 
     def step(i):
         j = i % nbuf
-        plan.forward(xs[j].data_ptr(), spectrum.buf.data_ptr(), bias_ptr, ys[j].data_ptr(),
-                     spectrum.workspace.data_ptr() if spectrum.workspace is not None else None,
+        plan.forward(xs[j].data_ptr(), spectrum.buf.data_ptr(), bias_ptr, ys[j].data_ptr(), ws_ptr,
                      torch.cuda.current_stream(dev).cuda_stream)
 
     steps, warmup = args.steps, args.warmup

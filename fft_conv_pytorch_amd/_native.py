@@ -5,10 +5,11 @@ an exception is raised.  The product path never computes on the CPU.
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import os
 import threading
-from typing import Dict, Optional, Tuple
+from typing import Optional, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libfftconv_amd.so"
@@ -16,12 +17,12 @@ LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, LIB_NAME)   # en
 
 FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
 PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
-    "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_transform_kernel", "fc_forward",
-    "fc_wgrad1d_slices", "fc_wgrad1d", "fc_debug_set_stamps", "fc_debug_grid",
+    "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_plan_layout", "fc_transform_kernel",
+    "fc_forward", "fc_forward_stamped", "fc_wgrad1d_slices", "fc_wgrad1d", "fc_debug_grid",
 )
 
 
@@ -83,8 +84,10 @@ def load_library() -> ctypes.CDLL:
         lib.fc_wgrad1d_slices.restype = i32
         lib.fc_wgrad1d.argtypes = [ctypes.POINTER(FcDesc), vp, vp, vp, i32, vp]
         lib.fc_wgrad1d.restype = i32
-        lib.fc_debug_set_stamps.argtypes = [vp, vp]
-        lib.fc_debug_set_stamps.restype = i32
+        lib.fc_forward_stamped.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.fc_forward_stamped.restype = i32
+        lib.fc_plan_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32 * 8)]
+        lib.fc_plan_layout.restype = i32
         lib.fc_debug_grid.argtypes = [vp]
         lib.fc_debug_grid.restype = ctypes.c_longlong
         if lib.fc_version() != ABI_VERSION:
@@ -131,9 +134,12 @@ def _raise(lib, status: int):
 
 
 class Plan:
-    """Owns one ``fc_plan`` (immutable after creation; shareable between threads)."""
+    """Owns one ``fc_plan`` (immutable after creation; shareable between threads and streams).
 
-    def __init__(self, key: Tuple):
+    The library builds a plan for the HIP device that is current at creation (twiddle tables, work list,
+    CU count): create it under ``torch.cuda.device(index)`` and pass that index as ``device_index``."""
+
+    def __init__(self, key: Tuple, device_index: int = 0):
         (ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode, has_bias, tile_hint,
          transposed, output_padding) = key
         lib = load_library()
@@ -153,12 +159,23 @@ class Plan:
         if st != FC_OK:
             _raise(lib, st)
         self._lib, self._h, self.key = lib, handle, key
+        self.device_index = int(device_index)
         out = (ctypes.c_int64 * 3)()
         lib.fc_output_shape(handle, ctypes.byref(out))
         self.out_spatial = tuple(int(out[i]) for i in range(ndim))
         self.spectrum_bytes = int(lib.fc_kernel_spectrum_bytes(handle))
         self.workspace_bytes = int(lib.fc_workspace_bytes(handle))
         self.tile = int(lib.fc_plan_tile(handle))
+        lay = (ctypes.c_int32 * 8)()
+        lib.fc_plan_layout(handle, ctypes.byref(lay))
+        # what the byte layout of the kernel spectrum depends on besides the descriptor: two plans with
+        # equal signatures accept each other's spectra (used by the multi-GPU broadcast)
+        self.layout = tuple(int(v) for v in lay)
+        self._stamps = None
+
+    def signature(self) -> Tuple:
+        """(spectrum bytes, layout words) -- equal on two plans iff a kernel spectrum is interchangeable."""
+        return (self.spectrum_bytes,) + self.layout
 
     def transform_kernel(self, weight_ptr: int, w_hat_ptr: int, workspace_ptr: Optional[int], stream: int):
         st = self._lib.fc_transform_kernel(self._h, weight_ptr, w_hat_ptr, workspace_ptr, stream)
@@ -167,12 +184,18 @@ class Plan:
 
     def forward(self, x_ptr: int, w_hat_ptr: int, bias_ptr: Optional[int], y_ptr: int,
                 workspace_ptr: Optional[int], stream: int):
-        st = self._lib.fc_forward(self._h, x_ptr, w_hat_ptr, bias_ptr, y_ptr, workspace_ptr, stream)
+        if self._stamps is not None:      # profiling run (scripts/phase_profile.py)
+            st = self._lib.fc_forward_stamped(self._h, x_ptr, w_hat_ptr, bias_ptr, y_ptr, workspace_ptr, stream,
+                                              self._stamps)
+        else:
+            st = self._lib.fc_forward(self._h, x_ptr, w_hat_ptr, bias_ptr, y_ptr, workspace_ptr, stream)
         if st != FC_OK:
             _raise(self._lib, st)
 
     def debug_set_stamps(self, ptr: Optional[int]):
-        self._lib.fc_debug_set_stamps(self._h, ptr)
+        """Profiling hook of this Python handle (the native plan stays immutable): while set, ``forward``
+        goes through ``fc_forward_stamped`` with this device buffer."""
+        self._stamps = ptr
 
     def debug_grid(self) -> int:
         return int(self._lib.fc_debug_grid(self._h))
@@ -186,20 +209,36 @@ class Plan:
             pass
 
 
-_plans: Dict[Tuple, Plan] = {}
+# Plan cache keyed on (device, descriptor): least-recently-used, bounded -- variable-length inputs would
+# otherwise keep one plan (and its device work list) alive per shape ever seen.  An evicted plan is
+# destroyed when the last KernelSpectrum / module that still refers to it lets go.
+PLAN_CACHE_SIZE = int(os.environ.get("FFTCONV_PLAN_CACHE", "128"))
+_plans: "collections.OrderedDict[Tuple, Plan]" = collections.OrderedDict()
 _plans_lock = threading.Lock()
 
 
-def get_plan(device_index: int, key: Tuple) -> Plan:
-    """Plan cache keyed on (device, descriptor)."""
+def lookup_plan(device_index: int, key: Tuple) -> Optional[Plan]:
     full = (device_index,) + key
-    plan = _plans.get(full)
-    if plan is None:
-        with _plans_lock:
-            plan = _plans.get(full)
-            if plan is None:
-                plan = Plan(key)
-                _plans[full] = plan
+    with _plans_lock:
+        plan = _plans.get(full)
+        if plan is not None:
+            _plans.move_to_end(full)
+        return plan
+
+
+def get_plan(device_index: int, key: Tuple) -> Plan:
+    """Cached plan for (device, descriptor); creates it on the CURRENT HIP device, which the caller
+    must have set to ``device_index`` (``functional._plan_for`` does)."""
+    full = (device_index,) + key
+    with _plans_lock:
+        plan = _plans.get(full)
+        if plan is None:
+            plan = Plan(key, device_index)
+            _plans[full] = plan
+            while len(_plans) > max(1, PLAN_CACHE_SIZE):
+                _plans.popitem(last=False)
+        else:
+            _plans.move_to_end(full)
     return plan
 
 

@@ -101,14 +101,18 @@ def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilati
     from . import _native
     desc = _native.conv_desc(1, x.shape[0], x.shape[1], wshape[0], groups, (x.shape[2],), (wshape[2],), stride, padding,
                              dilation, _native.PAD_MODES[padding_mode])
-    slices = _native.wgrad1d_slices(desc)
-    if slices == 0:
-        return None
-    x = x.contiguous()
-    grad = grad.contiguous()
-    part = torch.empty((slices,) + tuple(wshape), device=x.device, dtype=torch.float32)
-    _native.wgrad1d(desc, x.data_ptr(), grad.data_ptr(), part.data_ptr(), slices,
-                    torch.cuda.current_stream(x.device).cuda_stream)
+    if grad.device != x.device:
+        raise ValueError(f"gradient is on {grad.device} but the signal is on {x.device}")
+    # the library sizes the launch for, and keeps its twiddle tables on, the CURRENT device
+    with torch.cuda.device(x.device):
+        slices = _native.wgrad1d_slices(desc)
+        if slices == 0:
+            return None
+        x = x.contiguous()
+        grad = grad.contiguous()
+        part = torch.empty((slices,) + tuple(wshape), device=x.device, dtype=torch.float32)
+        _native.wgrad1d(desc, x.data_ptr(), grad.data_ptr(), part.data_ptr(), slices,
+                        torch.cuda.current_stream(x.device).cuda_stream)
     return part[0] if slices == 1 else part.sum(dim=0)
 
 
@@ -150,6 +154,60 @@ class FFTConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             d_kernel = _grad_weight(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation, groups,
                                     padding_mode)
+        if has_bias and ctx.needs_input_grad[2]:
+            d_bias = grad.sum(dim=[0] + list(range(2, grad.ndim)))
+        return d_signal, d_kernel, d_bias, None, None, None, None, None, None
+
+
+class FFTConvTransposeFunction(torch.autograd.Function):
+    """``fft_conv_transpose`` with gradients (the reference's transposed op is
+    differentiable through its rfftn/einsum/irfftn graph and its tests pin dW and db:
+    /root/reference/tests/test_functional_transpose.py:73-124).  With y = convT(x, W), W of shape
+    (Cin, Cout/g, *k):
+
+        dX = conv(dY, W)                  the ordinary convolution with the same hyper-parameters: a forward plan
+                                          (W read as a conv weight with Cin outputs and Cout/g inputs per group)
+        dW = the weight gradient of that  convolution, with dY as its signal and x as its output gradient
+        db = sum of dY over batch and space
+    """
+
+    @staticmethod
+    def forward(ctx, signal: Tensor, kernel: Tensor, bias: Optional[Tensor], stride: Tuple[int, ...],
+                padding: Tuple[int, ...], output_padding: Tuple[int, ...], dilation: Tuple[int, ...], groups: int,
+                spectrum):
+        plan = F_._plan_for(signal, kernel, bias, stride, padding, dilation, groups, "constant",
+                            transposed=True, output_padding=output_padding)
+        if spectrum is None or spectrum.plan is not plan:
+            spectrum = F_.transform_kernel(plan, kernel)
+        ctx.save_for_backward(signal, kernel)
+        ctx.conf = (stride, padding, dilation, groups, bias is not None)
+        return F_._forward_native(signal, spectrum, bias)
+
+    @staticmethod
+    def backward(ctx, grad: Tensor):
+        signal, kernel = ctx.saved_tensors
+        stride, padding, dilation, groups, has_bias = ctx.conf
+        grad = grad.contiguous()
+        n = grad.ndim - 2
+        in_spatial = tuple(signal.shape[2:])
+        # extent of conv(dY, W) per axis: >= the input extent; larger only when output_padding >= stride
+        conv_sp = tuple((grad.shape[2 + i] + 2 * padding[i] - dilation[i] * (kernel.shape[2 + i] - 1) - 1) // stride[i] + 1
+                        for i in range(n))
+        d_signal = d_kernel = d_bias = None
+        if ctx.needs_input_grad[0]:
+            dx = F_.fft_conv(grad, kernel.detach(), None, stride=stride, padding=padding, dilation=dilation,
+                             groups=groups)
+            if conv_sp != in_spatial:
+                dx = dx[(slice(None), slice(None)) + tuple(slice(0, s) for s in in_spatial)].contiguous()
+            d_signal = dx
+        if ctx.needs_input_grad[1]:
+            xg = signal.detach()
+            if conv_sp != in_spatial:     # rows past the input contribute nothing: zero-extend (data movement)
+                flat = []
+                for i in reversed(range(n)):
+                    flat += [0, conv_sp[i] - in_spatial[i]]
+                xg = F.pad(xg, flat)
+            d_kernel = _grad_weight(grad, xg, tuple(kernel.shape), stride, padding, dilation, groups, "constant")
         if has_bias and ctx.needs_input_grad[2]:
             d_bias = grad.sum(dim=[0] + list(range(2, grad.ndim)))
         return d_signal, d_kernel, d_bias, None, None, None, None, None, None

@@ -92,6 +92,36 @@ int get_twiddles(const fc::TileImpl* t, Twiddles* out) {
   return FC_OK;
 }
 
+// Twiddle tables of an already prepared (device, tile) pair: never allocates (hot-call side of get_twiddles).
+int find_twiddles(const fc::TileImpl* t, Twiddles* out) {
+  int dev = 0;
+  FC_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_tw_mutex);
+  auto it = g_tw.find(std::make_pair(dev, t->T));
+  if (it == g_tw.end())
+    return fail(FC_ERR_INVALID, "device tables for the %d-point tile are not prepared on device %d "
+                "(call fc_wgrad1d_slices on this device first)", t->T, dev);
+  *out = it->second;
+  return FC_OK;
+}
+
+// CU count of the current device, queried once per device.
+int current_device_cus(int* cus_out) {
+  static std::mutex m;
+  static std::map<int, int> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = cache.find(dev);
+  if (it == cache.end()) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+    it = cache.emplace(dev, cus).first;
+  }
+  *cus_out = it->second;
+  return 1;
+}
+
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
 }  // namespace
@@ -109,7 +139,6 @@ struct fc_plan {
   int V, ntiles, Lfull;
   size_t lds_conv, lds_spec;
   size_t spectrum_bytes, workspace_bytes;
-  void* debug_stamps;   // profiling hook (fc_debug_set_stamps)
   // ---- N-d (2-D / 3-D): axis 0 = fused (outermost), axis nd-1 = rows (x), middle axis only in 3-D
   const fc::TileImpl* tx;     // rows (last axis), full-length FFT
   const fc::TileImpl* tm;     // middle axis (3-D), full-length FFT
@@ -134,6 +163,7 @@ struct fc_plan {
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
+  int exp_sleep, exp_prio, exp_pref;   // tuning knobs of the batch-sharing kernel (environment, read at plan creation)
 };
 
 extern "C" {
@@ -326,9 +356,8 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   const char* env = getenv("FFTCONV_PERS");
   const int want = env ? atoi(env) : -1;            // -1 auto, 0 general kernel only, n force nb = n
   const bool fast_ok = want != 0 && fast_path_eligible(p);
-  int dev = 0, cus = 256;
-  FC_HIP(hipGetDevice(&dev));
-  FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int cus = 256;
+  if (!current_device_cus(&cus)) return fail(FC_ERR_HIP, "cannot query the current device");
   const int64_t per_item_units = (int64_t)p->n_ochunks * p->G;
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
   struct Cand { int T, nb, wgs_per_cu; double t_item; };
@@ -378,9 +407,8 @@ static int plan_1d_persistent(fc_plan* p) {
   const fc_desc& d = p->d;
   if (!p->wide && !fast_path_eligible(p)) return FC_OK;
   const fc::TileImpl* t = p->tile;
-  int dev = 0, cus = 256;
-  FC_HIP(hipGetDevice(&dev));
-  FC_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  int cus = 256;
+  if (!current_device_cus(&cus)) return fail(FC_ERR_HIP, "cannot query the current device");
   const int64_t B = d.batch * p->ph;                 // virtual batch (dilation phases)
   int nb = p->pers_nb_choice;
   if (d.tile_hint && !p->wide) {                    // explicit tile: FFTCONV_PERS picks the flavour (default general)
@@ -619,6 +647,12 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
     }
   }
   set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
+  {
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    p->exp_sleep = env_int("FFTCONV_EXP_SLEEP", 0);
+    p->exp_prio = env_int("FFTCONV_EXP_PRIO", 0);
+    p->exp_pref = env_int("FFTCONV_EXP_PREF", 0);
+  }
 
   int rc;
   if (d.ndim == 1) rc = plan_1d(p);
@@ -671,11 +705,10 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   if (nseg > 64) return 0;
   const int64_t V = t->T - kd_seg + 1, ntiles = (Lout + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
   if (n_items > 0x3fffffff) return 0;
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) != hipSuccess) return 0;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  const char* env = getenv("FFTCONV_DIAG");
-  g->diag = (!env || atoi(env) != 0) && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 &&
+  int cus = 256;
+  if (!current_device_cus(&cus)) return 0;
+  static const bool diag_on = !getenv("FFTCONV_DIAG") || atoi(getenv("FFTCONV_DIAG")) != 0;
+  g->diag = diag_on && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 &&
             t->wgrad1d_diag != nullptr;
   const int nb = g->diag ? 1 : t->wgrad_nb;
   g->t = t; g->kd_seg = (int)kd_seg; g->seg_taps = (int)ks; g->nseg = (int)nseg; g->V = (int)V; g->ntiles = (int)ntiles;
@@ -697,7 +730,10 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
 int fc_wgrad1d_slices(const fc_desc* desc) {
   if (!desc) return 0;
   WgradGeom g;
-  return wgrad_geometry(*desc, &g) ? g.slices : 0;
+  if (!wgrad_geometry(*desc, &g)) return 0;
+  Twiddles tw;                                   // first use on this device: build the tables here, not in the launch
+  if (get_twiddles(g.t, &tw) != FC_OK) return 0;
+  return g.slices;
 }
 
 int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream) {
@@ -706,7 +742,7 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
   if (!wgrad_geometry(*desc, &g)) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad1d does not cover this shape");
   if (slices != g.slices) return fail(FC_ERR_INVALID, "partial holds %d slices, the plan needs %d", slices, g.slices);
   Twiddles tw;
-  int rc = get_twiddles(g.t, &tw);
+  int rc = find_twiddles(g.t, &tw);
   if (rc != FC_OK) return rc;
   const fc_desc& d = *desc;
   fc::WGradArgs a;
@@ -732,9 +768,16 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
   return FC_OK;
 }
 
-int fc_debug_set_stamps(fc_plan* plan, void* device_buffer) {
-  if (!plan) return fail(FC_ERR_INVALID, "null argument");
-  plan->debug_stamps = device_buffer;
+int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
+  if (!plan || !layout) return fail(FC_ERR_INVALID, "null argument");
+  const fc_plan& p = *plan;
+  layout[0] = p.tile ? p.tile->T : 0;
+  layout[1] = p.ph; layout[2] = p.nseg; layout[3] = p.seg_taps;
+  layout[4] = p.diag; layout[5] = p.bd_gs; layout[6] = p.wide; layout[7] = p.pers_nb;
+  if (p.nd != 1) {   // N-d: the spectrum is laid out over the row / middle-axis transform lengths too
+    layout[1] = p.tx ? p.tx->T : 0; layout[2] = p.tm ? p.tm->T : 0; layout[3] = p.nd_cob;
+    layout[4] = layout[5] = layout[6] = layout[7] = 0;
+  }
   return FC_OK;
 }
 
@@ -744,7 +787,7 @@ long long fc_debug_grid(const fc_plan* plan) {
     const long long ncol = plan->nd == 2 ? plan->Fx : (long long)plan->Fx * plan->tm->T;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
   }
-  if (plan->pers_nb) return plan->pers_items;
+  if (plan->pers_nb) return (long long)plan->pers_items * 16;   // one record per wave (up to 16) of every work item
   return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->G;
 }
 
@@ -823,6 +866,11 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
 
 int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y, void* workspace,
                void* hip_stream) {
+  return fc_forward_stamped(plan, x, w_hat, bias, y, workspace, hip_stream, nullptr);
+}
+
+int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
+                       void* workspace, void* hip_stream, void* stamps) {
   if (!plan || !x || !w_hat || !y) return fail(FC_ERR_INVALID, "null argument");
   (void)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
@@ -838,8 +886,9 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
-    a.stamps = (unsigned long long*)p.debug_stamps;
+    a.stamps = (unsigned long long*)stamps;
     a.segmented = p.nseg > 1; a.pos_shift = 0;
+    a.exp_sleep = p.exp_sleep; a.exp_prio = p.exp_prio; a.exp_pref = p.exp_pref;
     if (p.pers_nb) {
       for (int j = 0; j < p.nseg; ++j) {
         fc::Conv1dPersArgs pa;
@@ -898,7 +947,7 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
   f.Cig_pad = p.Cig_pad; f.Cog_pad = p.nd_Cog_pad; f.cob = p.nd_cob; f.n_ochunks = p.nd_Cog_pad / p.nd_cob;
   f.Kd = (int)p.kd[0]; f.V = p.V; f.ntiles = p.ntiles; f.Lfull = p.Lfull; f.NVo = (int)p.out_sp[0];
   f.stride = p.ostride[0]; f.accumulate = p.accumulate; f.NLEN = p.Sp[0];
-  f.stamps = (unsigned long long*)p.debug_stamps;
+  f.stamps = (unsigned long long*)stamps;
 
   fc::RowsC2RArgs o{};
   o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;

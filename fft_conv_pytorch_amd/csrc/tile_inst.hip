@@ -3,6 +3,7 @@
 // geometries compile in parallel.
 #include "fc_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 
 #ifndef FC_P
@@ -19,22 +20,31 @@ constexpr int kNSEQ_R = kNSEQ_C / 2;
 constexpr int kLSEQP = SeqLayout<GG>::LSEQP;
 constexpr int kFusedMaxCib = (8 * kLSEQP * 8 <= 160 * 1024 && 8 * GG::TS <= 1024) ? 8 : 4;
 
-// Opt in to > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup).  Done once per
-// kernel with the full 160 KiB so nothing but the launch happens on later calls
-// (launches may be under HIP-graph capture).
+// Opt in to > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup).  Done once per kernel AND device with
+// the full 160 KiB so nothing but the launch happens on later calls (launches may be under HIP-graph
+// capture).  The attribute belongs to the function on the current device, so the "done" state is a bit per
+// device ordinal; the flag is atomic because plans are shared between threads (a duplicate
+// hipFuncSetAttribute from two racing first calls is harmless).
+struct LdsOptIn {
+  std::atomic<unsigned long long> mask{0};
+};
 template <class K>
-hipError_t ensure_lds(K kernel, size_t lds, bool* done) {
-  if (lds <= 64 * 1024 || *done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e == hipSuccess) *done = true;
+hipError_t ensure_lds(K kernel, size_t lds, LdsOptIn* done) {
+  if (lds <= 64 * 1024) return hipSuccess;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && (done->mask.load(std::memory_order_acquire) >> dev & 1ull)) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess && tracked) done->mask.fetch_or(1ull << dev, std::memory_order_release);
   return e;
 }
 
 template <int CIB>
 hipError_t launch_conv1d(const Conv1dArgs& a, int grid, size_t lds, hipStream_t st) {
   auto k = conv1d_fused_kernel<FC_P, FC_S, CIB, FC_NT>;
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(FC_NT), lds, st, a);
@@ -52,7 +62,7 @@ hipError_t conv1d_dispatch(int cib, const Conv1dArgs& a, int grid, size_t lds, h
 
 hipError_t spec1d_dispatch(const Spec1dArgs& a, int grid, size_t lds, hipStream_t st) {
   auto k = spectrum1d_kernel<FC_P, FC_S, FC_NT>;
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(FC_NT), lds, st, a);
@@ -63,7 +73,7 @@ hipError_t rows_r2c_dispatch(const RowsR2CArgs& a, hipStream_t st) {
   constexpr int NT = kNSEQ_R * GG::TS;
   auto k = rows_r2c_kernel<FC_P, FC_S, kNSEQ_R, NT>;
   const size_t lds = (size_t)kNSEQ_R * kLSEQP * sizeof(float2);
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
@@ -80,7 +90,7 @@ hipError_t c2c_dispatch(const C2CArgs& a, hipStream_t st) {
   const long long nbb = (a.NB + kNSEQ_C - 1) / kNSEQ_C;
   const long long grid = (long long)a.NA * a.NC * nbb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  static bool done = false;
+  static LdsOptIn done;
   if (INV) {
     auto k = c2c_inv_kernel<FC_P, FC_S, kNSEQ_C, NT>;
     hipError_t e = ensure_lds(k, lds, &done);
@@ -99,7 +109,7 @@ hipError_t rows_c2r_dispatch(const RowsC2RArgs& a, hipStream_t st) {
   constexpr int NT = kNSEQ_R * GG::TS;
   auto k = rows_c2r_kernel<FC_P, FC_S, kNSEQ_R, NT>;
   const size_t lds = (size_t)kNSEQ_R * kLSEQP * sizeof(float2);
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
@@ -125,7 +135,7 @@ hipError_t launch_fusedc_nb(const FusedCArgs& a, hipStream_t st) {
     constexpr int NT = NB * CIB * GG::TS;
     auto k = fusedc_kernel<FC_P, FC_S, CIB, NB, NT>;
     const size_t lds = (size_t)(a.accumulate ? 2 : 1) * NB * CIB * kLSEQP * sizeof(float2);
-    static bool done = false;
+    static LdsOptIn done;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;
     const long long nbb = (a.B + NB - 1) / NB;
@@ -172,12 +182,12 @@ constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_
 
 // batch-sharing kernel builds: PHASES (dilation as phases) x DIAG (depthwise blocks); the plain one keeps its
 // immediate offsets and is the only one the headline configuration runs
-template <int NB, bool PHASES, bool DIAG, bool SEG = false>
+template <int NB, bool PHASES, bool DIAG, bool SEG = false, int PREF = 0>
 hipError_t launch_pers_variant(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   constexpr int NT = NB * 4 * GG::TS;
   const size_t lds = pers_lds_bytes(NB);
-  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG>;
-  static bool done = false;
+  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PREF>;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
@@ -195,6 +205,18 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
     if (ph && dg) return launch_pers_variant<NB, true, true>(a, grid, st);
     if (ph) return launch_pers_variant<NB, true, false>(a, grid, st);
     if (dg) return launch_pers_variant<NB, false, true>(a, grid, st);
+#if FC_P == 32 && FC_S == 1
+    if constexpr (NB == 4) switch (a.c.exp_pref) {      // one bin pair per thread: the whole spectrum share fits in registers
+      case 4: return launch_pers_variant<NB, false, false, false, 4>(a, grid, st);
+      case 13: return launch_pers_variant<NB, false, false, false, 13>(a, grid, st);
+      case 22: return launch_pers_variant<NB, false, false, false, 22>(a, grid, st);
+      case 30: return launch_pers_variant<NB, false, false, false, 30>(a, grid, st);
+      case 40: return launch_pers_variant<NB, false, false, false, 40>(a, grid, st);
+      case 3: return launch_pers_variant<NB, false, false, false, 3>(a, grid, st);
+      case 2: return launch_pers_variant<NB, false, false, false, 2>(a, grid, st);
+      default: break;
+    }
+#endif
     return launch_pers_variant<NB, false, false>(a, grid, st);
   }
 }
@@ -211,7 +233,7 @@ hipError_t wide_dispatch(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   constexpr int NT = kWideNb * 4 * GG::TS;
   auto k = conv1d_wide_kernel<FC_P, FC_S, kWideNb, NT>;
   const size_t lds = pers_lds_bytes(kWideNb);
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
@@ -228,7 +250,7 @@ hipError_t wgrad_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
   constexpr int NT = kWgradNb * 4 * GG::TS;
   auto k = wgrad1d_kernel<FC_P, FC_S, kWgradNb, NT>;
   const size_t lds = ((size_t)FC_P * GG::N2 + (size_t)kWgradNb * 4 * GG::LSEQ) * sizeof(float2);
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
@@ -238,7 +260,7 @@ hipError_t wgrad_diag_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
   constexpr int NT = 8 * GG::TS;
   auto k = wgrad1d_diag_kernel<FC_P, FC_S, NT>;
   const size_t lds = ((size_t)FC_P * GG::N2 + (size_t)8 * GG::LSEQ) * sizeof(float2);
-  static bool done = false;
+  static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);

@@ -34,10 +34,31 @@ def broadcast_buffer(make_local: Callable[[], torch.Tensor], like: Callable[[], 
     return buf
 
 
+def _plan_signatures_agree(plan, device, group) -> bool:
+    """True when every rank's plan lays the kernel spectrum out identically (same bytes, tile, dilation
+    handling, segmentation, channel blocking).  The 1-D planner looks at the LOCAL batch, and shards may
+    differ by one item (33 items on 2 ranks -> 17 + 16), so this is checked, not assumed."""
+    sig = torch.tensor(plan.signature(), dtype=torch.int64, device=device)
+    world = dist.get_world_size(group)
+    gathered = [torch.empty_like(sig) for _ in range(world)]
+    dist.all_gather(gathered, sig, group=group)
+    return all(torch.equal(g, gathered[0]) for g in gathered)
+
+
 def broadcast_kernel_spectrum(plan, kernel: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None):
     """Transform the kernel on rank ``src`` only and broadcast the spectrum (not the raw weights'
-    full-length FFT, which the reference would have needed: 8.4 MB at the metric configuration)."""
+    full-length FFT, which the reference would have needed: 8.4 MB at the metric configuration).
+
+    Collective: every rank of ``group`` must call it.  When the ranks' plans disagree on the spectrum
+    layout (unequal shards can make the planner pick another tile or dilation handling), a foreign
+    spectrum would be garbage or the wrong size: every rank then transforms its own copy of ``kernel``
+    instead -- all ranks reach the same decision from the same all-gathered signatures, so nobody is
+    left waiting in a broadcast."""
     from . import functional as F_
+
+    comm_device = kernel.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    if not _plan_signatures_agree(plan, comm_device, group):
+        return F_.transform_kernel(plan, kernel)
 
     holder = {}
 
@@ -47,9 +68,7 @@ def broadcast_kernel_spectrum(plan, kernel: torch.Tensor, src: int = 0, group: O
 
     def like():
         holder["spec"] = F_.KernelSpectrum(
-            plan, torch.empty(max(plan.spectrum_bytes, 16) // 4, dtype=torch.float32, device=kernel.device),
-            torch.empty(plan.workspace_bytes // 4, dtype=torch.float32, device=kernel.device)
-            if plan.workspace_bytes else None)
+            plan, torch.empty(max(plan.spectrum_bytes, 16) // 4, dtype=torch.float32, device=kernel.device))
         return holder["spec"].buf
 
     broadcast_buffer(make_local, like, src=src, group=group)
@@ -59,7 +78,8 @@ def broadcast_kernel_spectrum(plan, kernel: torch.Tensor, src: int = 0, group: O
 def fft_conv_sharded(signal_shard: torch.Tensor, kernel: torch.Tensor, bias=None, stride=1, padding=0, dilation=1,
                      groups: int = 1, padding_mode: str = "constant", src: int = 0,
                      group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
-    """Forward convolution of this rank's batch shard; the kernel spectrum comes from rank ``src``."""
+    """Forward convolution of this rank's batch shard; the kernel spectrum comes from rank ``src``
+    (every rank holds the same ``kernel``, as after loading one checkpoint)."""
     from . import functional as F_
 
     plan = F_._plan_for(signal_shard, kernel, bias, stride, padding, dilation, groups, padding_mode)

@@ -30,12 +30,40 @@ def _require_gpu_f32(name: str, t: Tensor):
 
 
 class KernelSpectrum:
-    """A weight tensor transformed for one plan (rows a2 + a6); reusable while the weight is unchanged."""
+    """A weight tensor transformed for one plan (rows a2 + a6); reusable while the weight is unchanged.
 
-    __slots__ = ("plan", "buf", "workspace")
+    Read-only once built: the scratch area of the N-d passes is NOT part of it -- every forward call takes
+    its own workspace from torch's (stream-ordered) allocator, so one spectrum can serve several streams."""
 
-    def __init__(self, plan, buf, workspace):
-        self.plan, self.buf, self.workspace = plan, buf, workspace
+    __slots__ = ("plan", "buf")
+
+    def __init__(self, plan, buf):
+        self.plan, self.buf = plan, buf
+
+
+def _same_device(**tensors) -> torch.device:
+    """All tensors of one call must live on one device (else the kernels would be handed foreign pointers)."""
+    dev = None
+    for name, t in tensors.items():
+        if t is None:
+            continue
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError(f"fft_conv_pytorch_amd: `{name}` is on {t.device} but the signal is on {dev}; "
+                             f"all tensors of one call must be on the same device")
+    return dev
+
+
+def _device_index(dev: torch.device) -> int:
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
+def new_workspace(plan, device) -> Optional[Tensor]:
+    """Scratch area of one forward / transform call of an N-d plan (None for 1-D plans)."""
+    if not plan.workspace_bytes:
+        return None
+    return torch.empty(plan.workspace_bytes // 4, dtype=torch.float32, device=device)
 
 
 def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, groups, padding_mode, tile_hint=None,
@@ -83,34 +111,49 @@ def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, g
     _require_gpu_f32("kernel", kernel)
     if bias is not None:
         _require_gpu_f32("bias", bias)
-    return _native.get_plan(signal.device.index or 0, key)
+    dev = _same_device(signal=signal, kernel=kernel, bias=bias)
+    index = _device_index(dev)
+    plan = _native.lookup_plan(index, key)
+    if plan is None:
+        # the library allocates twiddle tables and work lists on the CURRENT HIP device and sizes the work
+        # list for its CU count: create the plan with the tensors' device current
+        with torch.cuda.device(index):
+            plan = _native.get_plan(index, key)
+    return plan
 
 
 def transform_kernel(plan, kernel: Tensor) -> KernelSpectrum:
     """Kernel transform (dilate, zero-pad, FFT, conjugate) on the device; rows a2 + a6."""
     _require_gpu_f32("kernel", kernel)
     kernel = kernel.detach().contiguous()
+    if _device_index(kernel.device) != plan.device_index:
+        raise ValueError(f"kernel is on {kernel.device} but the plan was made for cuda:{plan.device_index}")
     with torch.cuda.device(kernel.device):
         buf = torch.empty(max(plan.spectrum_bytes, 16) // 4, dtype=torch.float32, device=kernel.device)
-        ws = torch.empty(plan.workspace_bytes // 4, dtype=torch.float32, device=kernel.device) if plan.workspace_bytes else None
+        ws = new_workspace(plan, kernel.device)      # scratch of this call only
         stream = torch.cuda.current_stream(kernel.device).cuda_stream
         plan.transform_kernel(kernel.data_ptr(), buf.data_ptr(), ws.data_ptr() if ws is not None else None, stream)
-    return KernelSpectrum(plan, buf, ws)
+    return KernelSpectrum(plan, buf)
 
 
 def _launch_forward(signal: Tensor, spectrum: KernelSpectrum, bias_c: Optional[Tensor]) -> Tensor:
     plan = spectrum.plan
     out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=torch.float32, device=signal.device)
+    ws = new_workspace(plan, signal.device)
     stream = torch.cuda.current_stream(signal.device).cuda_stream
     plan.forward(signal.data_ptr(), spectrum.buf.data_ptr(), bias_c.data_ptr() if bias_c is not None else None,
-                 out.data_ptr(), spectrum.workspace.data_ptr() if spectrum.workspace is not None else None, stream)
+                 out.data_ptr(), ws.data_ptr() if ws is not None else None, stream)
     return out
 
 
 def _forward_native(signal: Tensor, spectrum: KernelSpectrum, bias: Optional[Tensor]) -> Tensor:
     signal = signal.detach().contiguous()
     bias_c = bias.detach().contiguous() if bias is not None else None
-    if torch.cuda.current_device() == signal.device.index:      # the common case: no device switch to pay for
+    index = _device_index(signal.device)
+    if spectrum.plan.device_index != index or spectrum.buf.device != signal.device:
+        raise ValueError(f"signal is on {signal.device} but the kernel spectrum / plan belong to "
+                         f"cuda:{spectrum.plan.device_index}")
+    if torch.cuda.current_device() == index:      # the common case: no device switch to pay for
         return _launch_forward(signal, spectrum, bias_c)
     with torch.cuda.device(signal.device):
         return _launch_forward(signal, spectrum, bias_c)
@@ -177,9 +220,22 @@ def fft_conv_transpose(
     in/out channel swap are folded into the kernel transform, padding / output_padding only move
     the window of kept samples -- no intermediate tensor is materialised.
     """
-    plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, "constant",
-                     transposed=True, output_padding=output_padding)
-    spectrum = transform_kernel(plan, kernel)
+    return _fft_conv_transpose_impl(signal, kernel, bias, stride, padding, output_padding, dilation, groups, None)
+
+
+def _fft_conv_transpose_impl(signal, kernel, bias, stride, padding, output_padding, dilation, groups, spectrum,
+                             plan=None):
+    """Shared by the functional and the transposed modules (``spectrum`` / ``plan``: see ``_fft_conv_impl``)."""
+    if _needs_grad(signal, kernel, bias):
+        from .autograd import FFTConvTransposeFunction     # differentiable like the reference's op graph
+        n = signal.ndim - 2
+        return FFTConvTransposeFunction.apply(signal, kernel, bias, to_ntuple(stride, n), to_ntuple(padding, n),
+                                              to_ntuple(output_padding, n), to_ntuple(dilation, n), groups, spectrum)
+    if plan is None:
+        plan = _plan_for(signal, kernel, bias, stride, padding, dilation, groups, "constant",
+                         transposed=True, output_padding=output_padding)
+    if spectrum is None or spectrum.plan is not plan:
+        spectrum = transform_kernel(plan, kernel)
     return _forward_native(signal, spectrum, bias)
 
 

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 3
+#define FC_ABI_VERSION 4
 
 enum fc_status {
   FC_OK = 0,
@@ -81,6 +81,15 @@ size_t fc_workspace_bytes(const fc_plan* plan);
 /* FFT tile length chosen for the last (fused) axis, for reporting. */
 int fc_plan_tile(const fc_plan* plan);
 
+/* Everything the byte layout of the kernel spectrum depends on besides the descriptor itself:
+ * {tile, dilation phases, kernel segments, taps per segment, depthwise blocks, regrouped small groups,
+ * wide-input kernel, batch items per workgroup}.  Two plans of equal descriptor (up to the batch size),
+ * equal fc_kernel_spectrum_bytes() and equal layout words accept each other's fc_transform_kernel()
+ * output -- what a multi-GPU caller checks before broadcasting one rank's spectrum (the planner looks at
+ * the local batch size).  No counterpart in the reference (it re-transforms the kernel on every call,
+ * functional.py:71). */
+int fc_plan_layout(const fc_plan* plan, int32_t layout[8]);
+
 /* Kernel transform: dilation scatter + zero pad + real FFT + conjugate
  * (functional.py:49-57 and :71; rows a2, a6).  weight is (Cout, Cin/groups, *k)
  * contiguous fp32 on the device; w_hat receives fc_kernel_spectrum_bytes(). */
@@ -103,14 +112,19 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
  * and the row on chip; the result comes in `slices` partial tensors that the caller sums:
  *   partial is (slices, Cout, Cin/groups, K) fp32, fully written by the call.
  * fc_wgrad1d_slices returns the slice count for the current device, 0 when the shape is not covered
- * (the caller then differentiates through fc_forward plans instead). */
+ * (the caller then differentiates through fc_forward plans instead); it also builds the device tables
+ * the launch needs, so fc_wgrad1d itself never allocates or copies (call fc_wgrad1d_slices first, on the
+ * same device -- the caller needs its answer to size `partial` anyway). */
 int fc_wgrad1d_slices(const fc_desc* desc);
 int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream);
 
-/* Profiling hook (not part of the drop-in surface): when a device buffer of
- * 16 * fc_debug_grid(plan) uint64 is set, lane 0 of every workgroup of the fused
- * 1-D kernel stores the 100 MHz wall clock at its phase boundaries.  NULL = off. */
-int fc_debug_set_stamps(fc_plan* plan, void* device_buffer);
+/* Profiling variant of fc_forward (not part of the drop-in surface; the plan stays immutable):
+ * `stamps` is a device buffer of 16 * fc_debug_grid(plan) uint64 in which lane 0 of the waves of the
+ * fused kernels stores the 100 MHz wall clock at its phase boundaries (batch-sharing 1-D kernel: one
+ * record of 16 stamps per wave, 16 wave slots per work item).  The stamped launch drains its loads at
+ * two extra points: read shares, not totals. */
+int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
+                       void* workspace, void* hip_stream, void* stamps);
 long long fc_debug_grid(const fc_plan* plan);
 
 #ifdef __cplusplus

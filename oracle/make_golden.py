@@ -13,6 +13,9 @@ Fixture families:
   G1  the reference's own test grid (tests/test_functional.py:11-20), thinned
   G2  multi-channel groups, per-axis hyper-parameters, the four padding modes
   G3  the BASELINE.json configs: seed, input checksum, sampled outputs
+  G4  transposed convolution (forward outputs)
+  G5  gradients: the reference's own autograd (dX, dW, db of sum(y * gy) with a seeded gy) for forward and
+      transposed cases, including every BASELINE config at reduced batch / length
 """
 from __future__ import annotations
 
@@ -155,13 +158,117 @@ def make_g4(ref):
     print("G4:", len(cases), "cases")
 
 
+def g5_cases():
+    """(kind, case): kind 'fwd' uses fft_conv (kernel (Cout, Cin/g, *k)), 'tr' fft_conv_transpose (kernel (Cin, Cout/g, *k))."""
+    fwd = [
+        # the reference's grid values (tests/test_functional.py:11-20), one per axis combination of interest
+        dict(batch=2, cin=2, cout=3, groups=1, spatial=(7,), k=(2,), stride=1, padding=0, dilation=1, mode="constant"),
+        dict(batch=2, cin=3, cout=3, groups=3, spatial=(8,), k=(3,), stride=2, padding=1, dilation=2, mode="constant"),
+        dict(batch=2, cin=2, cout=2, groups=2, spatial=(8, 7), k=(3, 2), stride=(1, 2), padding=(1, 0), dilation=(2, 1), mode="constant"),
+        dict(batch=2, cin=3, cout=2, groups=1, spatial=(7, 8, 7), k=(2, 3, 2), stride=1, padding=1, dilation=1, mode="constant"),
+        # multi-channel groups, padding modes, strides (the reference never tests these)
+        dict(batch=2, cin=8, cout=8, groups=2, spatial=(300,), k=(9,), stride=1, padding=4, dilation=1, mode="constant"),
+        dict(batch=3, cin=6, cout=4, groups=2, spatial=(100,), k=(7,), stride=3, padding=5, dilation=2, mode="reflect"),
+        dict(batch=2, cin=4, cout=6, groups=1, spatial=(64,), k=(5,), stride=2, padding=3, dilation=1, mode="replicate"),
+        dict(batch=2, cin=5, cout=3, groups=1, spatial=(50,), k=(4,), stride=1, padding=6, dilation=3, mode="circular"),
+        dict(batch=2, cin=4, cout=4, groups=2, spatial=(20, 33), k=(3, 5), stride=(1, 2), padding=(2, 1), dilation=(2, 1), mode="constant"),
+        dict(batch=1, cin=3, cout=5, groups=1, spatial=(31, 18), k=(4, 3), stride=(2, 1), padding=(1, 2), dilation=(1, 2), mode="reflect"),
+        dict(batch=1, cin=4, cout=2, groups=2, spatial=(9, 12, 10), k=(2, 3, 4), stride=(1, 2, 1), padding=(1, 0, 2), dilation=(2, 1, 1), mode="constant"),
+        dict(batch=2, cin=3, cout=3, groups=3, spatial=(8, 8, 8), k=(3, 3, 3), stride=1, padding=1, dilation=1, mode="replicate"),
+        # several overlap-save tiles; the on-chip weight-gradient kernel (stride 1) and the plan fallback (stride 2)
+        dict(batch=2, cin=8, cout=8, groups=1, spatial=(5000,), k=(129,), stride=1, padding=64, dilation=1, mode="constant"),
+        dict(batch=2, cin=16, cout=24, groups=1, spatial=(3000,), k=(65,), stride=2, padding=32, dilation=1, mode="constant"),
+        dict(batch=2, cin=16, cout=16, groups=16, spatial=(4000,), k=(33,), stride=1, padding=16, dilation=1, mode="circular"),
+        # BASELINE.json configs at reduced batch / length (same channels, kernel, dilation, groups)
+        dict(batch=1, cin=8, cout=8, groups=1, spatial=(32768,), k=(128,), stride=1, padding=0, dilation=1, mode="constant", name="cfg0"),
+        dict(batch=2, cin=8, cout=8, groups=1, spatial=(32768,), k=(512,), stride=1, padding=0, dilation=1, mode="constant", name="cfgA_b2"),
+        dict(batch=1, cin=8, cout=8, groups=1, spatial=(256, 256), k=(31, 31), stride=1, padding=0, dilation=1, mode="constant", name="cfgB_b1_256"),
+        dict(batch=1, cin=8, cout=8, groups=1, spatial=(64, 64, 64), k=(9, 9, 9), stride=1, padding=0, dilation=1, mode="constant", name="cfgC_b1"),
+        dict(batch=1, cin=64, cout=64, groups=8, spatial=(1 << 16,), k=(257,), stride=1, padding=0, dilation=4, mode="constant", name="cfgD_b1_64k"),
+    ]
+    tr = [
+        dict(batch=2, cin=2, cout=3, groups=1, spatial=(7,), k=(2,), stride=1, padding=0, dilation=1, output_padding=0),
+        dict(batch=2, cin=3, cout=3, groups=3, spatial=(8,), k=(3,), stride=3, padding=1, dilation=2, output_padding=1),
+        dict(batch=2, cin=2, cout=2, groups=2, spatial=(8,), k=(3,), stride=4, padding=1, dilation=4, output_padding=2),
+        dict(batch=2, cin=2, cout=2, groups=1, spatial=(7,), k=(2,), stride=2, padding=0, dilation=3, output_padding=2),    # output_padding >= stride
+        dict(batch=2, cin=3, cout=2, groups=1, spatial=(7, 8), k=(2, 3), stride=(2, 3), padding=(1, 0), dilation=(1, 3), output_padding=(1, 2)),
+        dict(batch=2, cin=2, cout=3, groups=1, spatial=(7, 8, 7), k=(3, 2, 3), stride=2, padding=1, dilation=2, output_padding=1),
+        dict(batch=2, cin=6, cout=4, groups=2, spatial=(40, 37), k=(5, 4), stride=(2, 1), padding=(2, 1), dilation=(1, 2), output_padding=(1, 0)),
+        dict(batch=1, cin=4, cout=6, groups=1, spatial=(9, 10, 8), k=(3, 2, 3), stride=(2, 1, 2), padding=(1, 0, 2), dilation=1, output_padding=(1, 0, 1)),
+        dict(batch=2, cin=8, cout=8, groups=1, spatial=(3000,), k=(129,), stride=1, padding=64, dilation=1, output_padding=0),
+        dict(batch=1, cin=8, cout=16, groups=2, spatial=(1000,), k=(33,), stride=3, padding=5, dilation=2, output_padding=2),
+        dict(batch=2, cin=16, cout=8, groups=1, spatial=(2000,), k=(65,), stride=2, padding=3, dilation=1, output_padding=1),
+        dict(batch=2, cin=3, cout=5, groups=1, spatial=(50,), k=(4,), stride=2, padding=7, dilation=3, output_padding=1),
+    ]
+    return [("fwd", c) for c in fwd] + [("tr", c) for c in tr]
+
+
+G5_FULL_LIMIT = 20000      # tensors up to this many elements are stored whole, larger ones as 4096 samples + sum
+
+
+def _pack(store, key, arr, seed):
+    arr = np.ascontiguousarray(arr)
+    store[f"{key}_shape"] = np.array(arr.shape, dtype=np.int64)
+    store[f"{key}_absmax"] = np.array(float(np.abs(arr).max()))
+    if arr.size <= G5_FULL_LIMIT:
+        store[f"{key}_full"] = arr
+    else:
+        idx = np.random.default_rng(seed).integers(0, arr.size, 4096)
+        store[f"{key}_idx"], store[f"{key}_samp"] = idx, arr.reshape(-1)[idx]
+        store[f"{key}_sum"] = np.array(arr.astype(np.float64).sum())
+
+
+def make_g5(ref):
+    """Gradients from the REFERENCE's autograd graph (it has no custom backward: torch differentiates its
+    rfftn / einsum / irfftn ops; the reference's tests pin dW and db the same way,
+    tests/test_functional.py:62-117, tests/test_functional_transpose.py:73-124)."""
+    import torch
+    store = {}
+    cases = g5_cases()
+    for n, (kind, c) in enumerate(cases):
+        seed = 11000 + 5 * n
+        if kind == "fwd":
+            wshape = (c["cout"], c["cin"] // c["groups"]) + tuple(c["k"])
+        else:
+            wshape = (c["cin"], c["cout"] // c["groups"]) + tuple(c["k"])
+        x = torch.from_numpy(seeded(seed, c["batch"], c["cin"], *c["spatial"])).requires_grad_()
+        w = torch.from_numpy(seeded(seed + 1, *wshape)).requires_grad_()
+        b = torch.from_numpy(seeded(seed + 2, c["cout"])).requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if kind == "fwd":
+                y = ref.functional.fft_conv(x, w, bias=b, stride=c["stride"], padding=c["padding"], dilation=c["dilation"],
+                                            groups=c["groups"], padding_mode=c["mode"])
+            else:
+                y = ref.functional.fft_conv_transpose(x, w, bias=b, stride=c["stride"], padding=c["padding"],
+                                                      output_padding=c["output_padding"], dilation=c["dilation"],
+                                                      groups=c["groups"])
+        gy = torch.from_numpy(seeded(seed + 3, *y.shape))
+        y.backward(gy)
+        meta = dict(c)
+        meta.update(kind=kind, seed=seed, yshape=tuple(int(v) for v in y.shape))
+        store[f"meta{n}"] = np.array(repr(meta))
+        _pack(store, f"y{n}", y.detach().numpy(), seed + 10)
+        _pack(store, f"dx{n}", x.grad.numpy(), seed + 11)
+        _pack(store, f"dw{n}", w.grad.numpy(), seed + 12)
+        _pack(store, f"db{n}", b.grad.numpy(), seed + 13)
+        print("G5:", n, kind, c.get("name", ""), tuple(y.shape))
+    store["count"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(OUT_DIR, "g5_gradients.npz"), **store)
+    print("G5:", len(cases), "cases")
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     ref = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "g4":
         make_g4(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "g5":
+        make_g5(ref)
+        return
     make_g4(ref)
+    make_g5(ref)
 
     # ---- G1
     store = {}

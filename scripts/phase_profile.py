@@ -24,34 +24,40 @@ args = ap.parse_args()
 if args.tile:
     os.environ["FFTCONV_TILE"] = str(args.tile)
 dev = "cuda:0"
-layer = fca.FFTConv1d(args.ch, args.ch, args.k, dilation=args.dil, groups=args.groups).to(dev)
+layer = fca.FFTConv1d(args.ch, args.ch, args.k, dilation=args.dil, groups=args.groups).to(dev).eval()
 x = torch.randn(args.batch, args.ch, args.len, device=dev)
 for _ in range(3):
     y = layer(x)
 plan = layer.__dict__["_spectrum_cache"][1].plan
-grid = plan.debug_grid()
-buf = torch.zeros(grid * 16, dtype=torch.int64, device=dev)
+nrec = plan.debug_grid()                 # records of 16 stamps: one per wave (16 slots) of every work item
+buf = torch.zeros(nrec * 16, dtype=torch.int64, device=dev)
 plan.debug_set_stamps(buf.data_ptr())
 torch.cuda.synchronize()
 y = layer(x)
 torch.cuda.synchronize()
 plan.debug_set_stamps(None)
-st = buf.cpu().numpy().reshape(grid, 16).astype(np.float64) * 0.01   # 100 MHz ticks -> microseconds
+raw = buf.cpu().numpy().reshape(-1, 16, 16).astype(np.float64) * 0.01   # [item][wave][stamp], 100 MHz ticks -> us
+grid = raw.shape[0]
+nw = int((raw[:, :, 0] > 0).sum(axis=1).max())
+st = raw[:, 0, :]
 t0 = st[:, 0].min()
 names = ["start", "input landed", "passA done", "barrier1", "passB done", "barrier3", "mix done", "barrier4",
          "invA done", "barrier6", "stores issued", "stores landed"]
-print(f"grid={grid} tile={plan.tile}  kernel span = {st[:, 11].max() - t0:.2f} us")
-print(f"{'phase':16s} {'median dt':>10s} {'p10':>8s} {'p90':>8s}   (us, per workgroup, lane 0 of wave 0)")
+print(f"items={grid} waves/wg={nw} tile={plan.tile}  kernel span = {raw[:, :nw, 11].max() - t0:.2f} us")
+print(f"{'phase':16s} {'median dt':>10s} {'p10':>8s} {'p90':>8s}   (us, per work item, lane 0 of wave 0)")
 for i in range(1, 12):
     dt = st[:, i] - st[:, i - 1]
     print(f"{names[i]:16s} {np.median(dt):10.2f} {np.percentile(dt, 10):8.2f} {np.percentile(dt, 90):8.2f}")
+# per-wave view: when does each wave reach each stamp, relative to the item's earliest start (median over items)
+start = raw[:, :nw, 0].min(axis=1, keepdims=True)
+print("per-wave arrival (us after the item's first wave started; median over items)")
+print("stamp            " + " ".join(f"w{w:<5d}" for w in range(nw)))
+for i in range(12):
+    rel = raw[:, :nw, i] - start
+    print(f"{names[i]:16s} " + " ".join(f"{np.median(rel[:, w]):6.2f}" for w in range(nw)))
 life = st[:, 11] - st[:, 0]
-print(f"workgroup lifetime median {np.median(life):.2f} us; start times: p50 {np.median(st[:, 0] - t0):.2f} "
+print(f"work item lifetime median {np.median(life):.2f} us; start times: p50 {np.median(st[:, 0] - t0):.2f} "
       f"p90 {np.percentile(st[:, 0] - t0, 90):.2f} max {(st[:, 0] - t0).max():.2f} us")
-hist, edges = np.histogram(st[:, 0] - t0, bins=10)
-print("start-time histogram:", list(zip(np.round(edges[:-1], 1), hist)))
-# split by residency round (start time gap) to see whether later rounds run slower
-order = np.argsort(st[:, 0])
 half = st[:, 0] - t0 > 0.5 * np.median(life)
 for name, sel in (("first round", ~half), ("later rounds", half)):
     if sel.any():

@@ -52,6 +52,58 @@ def g4_cases():
         yield n, z[f"x{n}"], z[f"w{n}"], z[f"b{n}"], kw, z[f"y{n}"]
 
 
+def _unpack(z, key):
+    """Golden entry written by oracle/make_golden.py:_pack -- a full array, or samples + sum of a large one."""
+    shape = tuple(int(v) for v in z[f"{key}_shape"])
+    absmax = float(z[f"{key}_absmax"])
+    if f"{key}_full" in z.files:
+        return dict(full=z[f"{key}_full"], shape=shape, absmax=absmax)
+    return dict(idx=z[f"{key}_idx"], samples=z[f"{key}_samp"], total=float(z[f"{key}_sum"]), shape=shape, absmax=absmax)
+
+
+def g5_cases():
+    """Gradient fixtures from the reference's own autograd: yields (n, kind, meta, x, w, b, gy, gold) with
+    gold = dict(y=..., dx=..., dw=..., db=...) of _unpack entries; inputs are re-derived from the seed."""
+    z = np.load(os.path.join(GOLDEN, "g5_gradients.npz"))
+    for n in range(int(z["count"])):
+        meta = ast.literal_eval(str(z[f"meta{n}"]))
+        kind, seed = meta["kind"], meta["seed"]
+        if kind == "fwd":
+            wshape = (meta["cout"], meta["cin"] // meta["groups"]) + tuple(meta["k"])
+        else:
+            wshape = (meta["cin"], meta["cout"] // meta["groups"]) + tuple(meta["k"])
+        x = seeded(seed, meta["batch"], meta["cin"], *meta["spatial"])
+        w = seeded(seed + 1, *wshape)
+        b = seeded(seed + 2, meta["cout"])
+        gy = seeded(seed + 3, *meta["yshape"])
+        gold = {k: _unpack(z, f"{k}{n}") for k in ("y", "dx", "dw", "db")}
+        yield n, kind, meta, x, w, b, gy, gold
+
+
+def check_entry(arr, gold, tol):
+    """Compare an array with an _unpack entry; error is relative to the golden tensor's max magnitude."""
+    arr = np.asarray(arr)
+    assert tuple(arr.shape) == gold["shape"], (arr.shape, gold["shape"])
+    scale = max(gold["absmax"], 1e-30)
+    if "full" in gold:
+        err = float(np.abs(arr.astype(np.float64) - gold["full"].astype(np.float64)).max() / scale)
+    else:
+        got = arr.reshape(-1)[gold["idx"]].astype(np.float64)
+        err = float(np.abs(got - gold["samples"].astype(np.float64)).max() / scale)
+        tot = float(arr.astype(np.float64).sum())
+        assert abs(tot - gold["total"]) <= 1e-4 * scale * np.sqrt(arr.size) + 1e-3 * abs(gold["total"])
+    assert err <= tol, f"rel err {err:.3e} > {tol}"
+    return err
+
+
+def g5_kwargs(kind, meta):
+    if kind == "fwd":
+        return dict(stride=meta["stride"], padding=meta["padding"], dilation=meta["dilation"], groups=meta["groups"],
+                    padding_mode=meta["mode"])
+    return dict(stride=meta["stride"], padding=meta["padding"], output_padding=meta["output_padding"],
+                dilation=meta["dilation"], groups=meta["groups"])
+
+
 BASELINE_CONFIGS = {
     "cfg0": (1, 8, 8, 1, (32768,), (128,), 1),
     "cfgA": (32, 8, 8, 1, (32768,), (512,), 1),

@@ -58,3 +58,50 @@ def test_broadcast_and_bookkeeping_world2_gloo():
         for rank in range(world):
             ok, units, tmax = out[rank]
             assert ok and units == 33.0 and tmax == 2.0
+
+
+# ---- spectrum broadcast vs local transform: decided by the all-gathered plan signatures
+class _FakePlan:
+    def __init__(self, sig, nbytes=64):
+        self._sig, self.spectrum_bytes, self.workspace_bytes = sig, nbytes, 0
+
+    def signature(self):
+        return (self.spectrum_bytes,) + self._sig
+
+
+def _sig_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fft_conv_pytorch_amd import distributed as D, functional as F_
+        made = []
+
+        def fake_transform(plan, kernel):
+            made.append(1)
+            return F_.KernelSpectrum(plan, torch.full((16,), float(rank + 1)))
+
+        F_.transform_kernel = fake_transform
+        kernel = torch.zeros(4)
+        # equal layouts on both ranks: rank 0 transforms, rank 1 receives rank 0's spectrum
+        spec = D.broadcast_kernel_spectrum(_FakePlan((1024, 1, 1, 512, 0, 0, 0, 4)), kernel, src=0)
+        same = (len(made), float(spec.buf[0]))
+        # rank 1's planner picked another tile (unequal shards can do that): nobody broadcasts, everyone transforms
+        made.clear()
+        spec = D.broadcast_kernel_spectrum(_FakePlan((1024 if rank == 0 else 2048, 1, 1, 512, 0, 0, 0, 4)), kernel, src=0)
+        differ = (len(made), float(spec.buf[0]))
+        # equal tile but different byte size must not be broadcast either
+        made.clear()
+        spec = D.broadcast_kernel_spectrum(_FakePlan((1024, 1, 1, 512, 0, 0, 0, 4), nbytes=64 + 64 * rank), kernel, src=0)
+        size = (len(made), float(spec.buf[0]))
+        out[rank] = (same, differ, size)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_spectrum_broadcast_needs_agreeing_plan_signatures_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sig_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert out[0] == ((1, 1.0), (1, 1.0), (1, 1.0))
+        assert out[1] == ((0, 1.0), (1, 2.0), (1, 2.0))     # received once, then two local transforms

@@ -103,3 +103,122 @@ def test_scripts_and_entry_points_compile():
             py_compile.compile(os.path.join(ROOT, "scripts", name), doraise=True)
     for name in ("bench.py", "__graft_entry__.py"):
         py_compile.compile(os.path.join(ROOT, name), doraise=True)
+
+
+# ---------------------------------------------------------------- round 2: device handling, caches, signatures
+class _FakeCudaTensor:
+    """Just enough of a tensor for functional._plan_for's host-side checks (no device is touched)."""
+
+    def __init__(self, shape, index):
+        self.shape, self.ndim = torch.Size(shape), len(shape)
+        self.is_cuda, self.dtype = True, torch.float32
+        self.device = torch.device("cuda", index)
+
+
+def test_plan_is_created_on_the_tensors_device_not_the_current_one(monkeypatch):
+    """plans own device allocations, so they must be built with the TENSORS' device current
+    and cached under that device's ordinal -- also when another device is current."""
+    from fft_conv_pytorch_amd import _native, functional as F_
+    seen = {}
+
+    class Guard:
+        def __init__(self, index):
+            seen["guard"] = index
+
+        def __enter__(self):
+            seen["inside"] = True
+
+        def __exit__(self, *a):
+            seen["inside"] = False
+
+    def fake_get_plan(index, key):
+        seen["created_on"] = index
+        seen["created_inside_guard"] = seen.get("inside", False)
+        return "plan"
+
+    monkeypatch.setattr(F_.torch.cuda, "device", Guard)
+    monkeypatch.setattr(_native, "lookup_plan", lambda index, key: None)
+    monkeypatch.setattr(_native, "get_plan", fake_get_plan)
+    x, w = _FakeCudaTensor((2, 4, 64), 1), _FakeCudaTensor((6, 4, 5), 1)
+    assert F_._plan_for(x, w, None, 1, 0, 1, 1, "constant") == "plan"
+    assert seen["guard"] == 1 and seen["created_on"] == 1 and seen["created_inside_guard"]
+    # a cached plan is returned without switching devices
+    seen.clear()
+    monkeypatch.setattr(_native, "lookup_plan", lambda index, key: ("cached", index))
+    assert F_._plan_for(x, w, None, 1, 0, 1, 1, "constant") == ("cached", 1)
+    assert "guard" not in seen
+    # tensors of one call on different devices are refused before anything is launched
+    with pytest.raises(ValueError, match="same device"):
+        F_._plan_for(x, _FakeCudaTensor((6, 4, 5), 0), None, 1, 0, 1, 1, "constant")
+
+
+def test_plan_cache_is_bounded_lru(monkeypatch):
+    from fft_conv_pytorch_amd import _native
+
+    class FakePlan:
+        def __init__(self, key, device_index=0):
+            self.key, self.device_index = key, device_index
+
+    monkeypatch.setattr(_native, "Plan", FakePlan)
+    monkeypatch.setattr(_native, "PLAN_CACHE_SIZE", 3)
+    _native.clear_plan_cache()
+    try:
+        plans = [_native.get_plan(0, (i,)) for i in range(3)]
+        assert _native.get_plan(0, (0,)) is plans[0]            # hit: becomes the most recent
+        _native.get_plan(0, (3,))                               # evicts the least recently used = key 1
+        assert _native.lookup_plan(0, (1,)) is None
+        assert _native.lookup_plan(0, (0,)) is plans[0] and _native.lookup_plan(0, (2,)) is plans[2]
+        assert _native.lookup_plan(1, (0,)) is None             # the device ordinal is part of the key
+    finally:
+        _native.clear_plan_cache()
+
+
+def test_module_spectrum_cache_policy(monkeypatch):
+    """the spectrum cache may only be used when the weight provably did not change."""
+    from fft_conv_pytorch_amd import FFTConv1d, FFTConvTranspose1d, functional as F_
+    calls = []
+    monkeypatch.setattr(F_, "transform_kernel", lambda plan, w: calls.append(1) or ("spec", len(calls)))
+    for layer in (FFTConv1d(4, 4, 3), FFTConvTranspose1d(4, 4, 3)):
+        calls.clear()
+        plan = object()
+        layer.train()
+        assert layer._cached_spectrum(plan) is None and not calls       # training step: re-transform like the reference
+        with torch.no_grad():
+            s1 = layer._cached_spectrum(plan)                            # no grad: cache is usable
+            assert s1 is not None and layer._cached_spectrum(plan) is s1 and len(calls) == 1
+        layer.eval()
+        assert layer._cached_spectrum(plan) is s1                        # eval: same weight version -> reuse
+        with torch.no_grad():
+            layer.weight.mul_(2.0)                                       # version counter bumps
+        s2 = layer._cached_spectrum(plan)
+        assert s2 is not s1 and len(calls) == 2
+        layer.weight.data.mul_(2.0)                                      # invisible to any key ...
+        assert layer._cached_spectrum(plan) is s2
+        layer.invalidate_kernel_spectrum()                               # ... hence the explicit hook
+        assert layer._cached_spectrum(plan) is not s2 and len(calls) == 3
+        assert layer._cached_spectrum(object()) is not None and len(calls) == 4   # another plan: another spectrum
+        layer.cache_kernel_spectrum = False
+        assert layer._cached_spectrum(plan) is None
+        layer.cache_kernel_spectrum = True
+        torch.nn.utils.parametrizations.weight_norm(layer)               # weight is now a fresh temporary per access
+        assert layer._cached_spectrum(plan) is None
+
+
+def test_transposed_ops_route_through_autograd_when_grad_is_needed(monkeypatch):
+    """fft_conv_transpose must not silently detach."""
+    from fft_conv_pytorch_amd import autograd as A, functional as F_
+    hit = {}
+
+    class Probe:
+        @staticmethod
+        def apply(*args):
+            hit["args"] = args
+            return "routed"
+
+    monkeypatch.setattr(A, "FFTConvTransposeFunction", Probe)
+    x = torch.zeros(1, 2, 8)
+    w = torch.zeros(2, 3, 3, requires_grad=True)
+    assert F_.fft_conv_transpose(x, w, stride=2, output_padding=1) == "routed"
+    assert hit["args"][3:8] == ((2,), (0,), (1,), (1,), 1)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
+        F_.fft_conv_transpose(x, w)          # without grad it takes the plain (device) path

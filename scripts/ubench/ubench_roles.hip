@@ -1,0 +1,82 @@
+// ubench_roles.hip -- do LDS traffic and VALU work of the two waves of a SIMD overlap?  512-thread workgroups
+// (2 waves per SIMD).  Each half of the workgroup (waves 0-3 / waves 4-7; SIMD partners are waves w and w+4)
+// gets a role: 'L' = pass-A style LDS exchange only (32 ds_write_b64 + 32 ds_read_b64 per repetition),
+// 'V' = 32-point register FFT only (194 v_pk), 'B' = both back to back, '-' = idle.
+// Prints the median shader cycles per repetition of each half.  Diagnostic only.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../fft_conv_pytorch_amd/csrc/fft_engine.hpp"
+
+using namespace fc;
+
+__device__ __forceinline__ void do_lds(f2 (&v)[32], f2* seq, int n2) {
+#pragma unroll
+  for (int k1 = 0; k1 < 32; ++k1) seq[k1 * 33 + n2] = v[k1];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  lds_read_strided<32, 1>(v, seq + n2 * 33);
+  lds_arrive(v);
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void do_valu(f2 (&v)[32]) {
+  fft_regs<32, -1>(v);
+  v[0] = v[0] * mk2(0.03125f, 0.03125f);
+}
+
+__global__ __launch_bounds__(512, 2) void k(const f2* __restrict__ in, f2* __restrict__ out, unsigned long long* cyc, int R, int role0, int role1,
+                                            int prio) {
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  const int tid = threadIdx.x;
+  f2 v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = in[(size_t)i * 1024 + tid];
+  f2* seq = lds + (tid / 32) * (32 * 33);
+  const int n2 = tid % 32;
+  const int role = tid < 256 ? role0 : role1;
+  if (prio == 1 && tid < 256) __builtin_amdgcn_s_setprio(1);
+  if (prio == 2 && tid >= 256) __builtin_amdgcn_s_setprio(1);
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  if (role == 'L') { for (int r = 0; r < R; ++r) do_lds(v, seq, n2); }
+  else if (role == 'V') { for (int r = 0; r < R; ++r) do_valu(v); }
+  else if (role == 'B') { for (int r = 0; r < R; ++r) { do_valu(v); do_lds(v, seq, n2); } }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  f2 acc = v[0];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) acc = acc + v[i];
+  out[(size_t)blockIdx.x * 512 + tid] = acc;
+  if ((tid & 63) == 0) cyc[(size_t)blockIdx.x * 8 + tid / 64] = t1 - t0;
+}
+
+int main() {
+  f2 *in, *out;
+  unsigned long long* cyc;
+  hipMalloc(&in, 32 * 1024 * sizeof(f2));
+  hipMalloc(&out, 256 * 512 * sizeof(f2));
+  hipMalloc(&cyc, 256 * 8 * sizeof(unsigned long long));
+  std::vector<f2> h(32 * 1024);
+  for (size_t i = 0; i < h.size(); ++i) h[i] = f2{(float)(rand() % 1000) / 1000.f - 0.5f, (float)(rand() % 1000) / 1000.f - 0.5f};
+  hipMemcpy(in, h.data(), h.size() * sizeof(f2), hipMemcpyHostToDevice);
+  const size_t lds = 16 * 32 * 33 * sizeof(f2);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int R = 64;
+  const char* combos[] = {"L-", "-L", "V-", "-V", "LL", "VV", "LV", "VL", "BB", "B-"};
+  for (int prio = 0; prio < 3; ++prio)
+    for (const char* c : combos) {
+      if (prio && !(c[0] != '-' && c[1] != '-')) continue;
+      k<<<256, 512, lds>>>(in, out, cyc, R, c[0], c[1], prio);
+      k<<<256, 512, lds>>>(in, out, cyc, R, c[0], c[1], prio);
+      hipDeviceSynchronize();
+      std::vector<unsigned long long> hc(256 * 8);
+      hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
+      std::vector<unsigned long long> h0, h1;
+      for (int b = 0; b < 256; ++b)
+        for (int w = 0; w < 8; ++w) (w < 4 ? h0 : h1).push_back(hc[b * 8 + w]);
+      std::sort(h0.begin(), h0.end()); std::sort(h1.begin(), h1.end());
+      printf("roles %s prio %d : half0 %6.0f cycles/rep   half1 %6.0f cycles/rep\n", c, prio, (double)h0[h0.size() / 2] / R, (double)h1[h1.size() / 2] / R);
+    }
+  return 0;
+}

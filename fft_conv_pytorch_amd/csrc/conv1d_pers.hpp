@@ -42,7 +42,7 @@ __device__ __forceinline__ void wave_sleep(int n) {
 }
 
 template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false,
-          int PREF = 0>
+          int PREF = 0, bool SLOT = false, bool TWG = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const BufRsrc twAg = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));      // TWG: pass-A twiddles through L1 instead of LDS
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
 
   // ---- input samples of one item -> registers (unrolled buffer loads; border tiles get per-sample
@@ -160,10 +161,45 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       });
       if constexpr (PRE_A > 0) __builtin_amdgcn_sched_barrier(0);     // keep the requests up here
     }
-    if (a.exp_sleep > 0 && tid >= NT / 2) wave_sleep(a.exp_sleep);     // half-workgroup stagger (tuning knob)
+    // Ping-pong slots (SLOT): the two waves of a SIMD (wave w and w + NT/128) do NOT overlap their LDS and
+    // VALU work when they run the same stage at the same time (measured: the forward passes take the SUM of
+    // the two), but a wave that only moves data through LDS and a partner that only issues butterflies run
+    // side by side at full speed (scripts/ubench/ubench_roles.hip: "LV").  So the transforms are cut at their
+    // VALU / LDS boundaries by workgroup barriers and the second half of the workgroup runs one stage behind
+    // the first: in every slot one half is in a VALU stage while the other is in an LDS stage.
+    const bool h1 = tid >= NT / 2;
+    auto slot_bar = [&](bool on) { if (SLOT && on) __builtin_amdgcn_s_barrier(); };
+    if (a.exp_sleep > 0 && h1) wave_sleep(a.exp_sleep);     // half-workgroup stagger (older tuning knob)
     // (act_in is wave-uniform and the two passes of a sequence only need wave-level ordering)
-    if (act_in) {
-      if constexpr (PRE_A > 0) passA_fft_twiddle_store_lds_lowreg<G, -1>(v, zseq, tseq, twl);
+    if constexpr (SLOT) {
+      int j = 0;
+      slot_bar(h1);
+      if (act_in) {                                                        // V: butterflies + twiddles
+        if constexpr (TWG) passA_compute_gl<G, -1>(v, tseq, twAg);
+        else passA_compute_lds<G, -1>(v, tseq, twl);
+      }
+      stamp_item(a.stamps, it, 2);
+      slot_bar(true);
+      if (act_in) {                                                        // L: row stores, row loads
+        passA_store<G>(v, zseq, tseq);
+        seq_sync<G>();
+        stamp_item(a.stamps, it, 3);
+        passB_load<G>(v, zseq, tseq);
+        seq_sync<G>();
+      }
+      slot_bar(true);
+      if (act_in) j = passB_compute<G, -1>(v, tseq, twB);                   // V: butterflies
+      slot_bar(true);
+      if (act_in) {                                                        // L: natural-order stores
+        const int k1 = tseq >> G::LGS;
+        f2* dst = zseq + G::nat(k1 + P * P * j);
+#pragma unroll
+        for (int k = 0; k < P; ++k) dst[P * k] = v[k];
+      }
+      slot_bar(!h1);
+    } else if (act_in) {
+      if constexpr (TWG) passA_fft_twiddle_store<G, -1>(v, zseq, tseq, twAg);
+      else if constexpr (PRE_A > 0) passA_fft_twiddle_store_lds_lowreg<G, -1>(v, zseq, tseq, twl);
       else passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
       stamp_item(a.stamps, it, 2);
       seq_sync<G>();
@@ -349,19 +385,43 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     __syncthreads();
     stamp_item(a.stamps, it, 7);
     // the next item's samples travel from HBM while this item's inverse passes run
+    slot_bar(h1);
     if (more) fetch(wnext, vnext);
-    if (a.exp_sleep > 0 && tid >= NT / 2) wave_sleep(a.exp_sleep);
-    // ------------------------------------------------ inverse pass A'
-    if (act_in) {
+    if (a.exp_sleep > 0 && h1) wave_sleep(a.exp_sleep);
+    // ------------------------------------------------ inverse passes A', B' + store
+    int j = 0;
+    if constexpr (SLOT) {
+      if (act_in) {                                                        // L: natural-order loads
+        nat_load<G>(v, zseq, tseq);
+        seq_sync<G>();
+      }
+      slot_bar(true);
+      if (act_in) {                                                        // V
+        if constexpr (TWG) passA_compute_gl<G, +1>(v, tseq, twAg);
+        else passA_compute_lds<G, +1>(v, tseq, twl);
+      }
+      stamp_item(a.stamps, it, 8);
+      slot_bar(true);
+      if (act_in) {                                                        // L: row stores, row loads
+        passA_store<G>(v, zseq, tseq);
+        seq_sync<G>();
+        stamp_item(a.stamps, it, 9);
+        passB_load<G>(v, zseq, tseq);
+      }
+      slot_bar(true);
+      if (act_in) j = passB_compute<G, +1>(v, tseq, twB);                   // V (+ the global stores below)
+    } else if (act_in) {
       nat_load<G>(v, zseq, tseq);
       seq_sync<G>();
-      passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
+      if constexpr (TWG) passA_fft_twiddle_store<G, +1>(v, zseq, tseq, twAg);
+      else passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
       stamp_item(a.stamps, it, 8);
       seq_sync<G>();
       stamp_item(a.stamps, it, 9);
-      // ---------------------------------------------- inverse pass B' + store
       passB_load<G>(v, zseq, tseq);
-      const int j = passB_compute<G, +1>(v, tseq, twB);
+      j = passB_compute<G, +1>(v, tseq, twB);
+    }
+    if (act_in) {
       const int o1 = tseq >> G::LGS;
       const int vb = a.slot_tiles ? wi.b0 : wi.b0 + nb;
       const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
@@ -398,6 +458,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           if (nbase + P * k < limit) { y0[ystep * k] = v[k].x + bias0; y1[ystep * k] = v[k].y + bias1; }
       }
     }
+    slot_bar(!h1);
     stamp_item(a.stamps, it, 10);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }
     seq_sync<G>();     // this wave's sequences are free again (the mix barriers order the other waves)

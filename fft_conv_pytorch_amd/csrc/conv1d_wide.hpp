@@ -87,9 +87,14 @@ __global__ __launch_bounds__(NT, 2) void conv1d_wide_kernel(const Conv1dPersArgs
           v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
         }
       } else {
+        // The per-sample padded offsets do not depend on the chunk: left alone, hipcc hoists all 2 * P of them
+        // out of the chunk loop and keeps them live beside the running sums (42 spilled VGPRs).  The opaque
+        // copy ties them to this iteration.
+        int tpos = tile_pos;
+        asm volatile("" : "+s"(tpos));
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
-          const int pos = tile_pos + G::N2 * n1 + tseq;
+          const int pos = tpos + G::N2 * n1 + tseq;
           v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
           v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
         }

@@ -146,6 +146,8 @@ struct fc_plan {
   int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
   int padl[3], up[3], ostride[3];   // left pad in grid coordinates, source spread step, output decimation
   int Fx;                     // Tx/2 + 1
+  int nxt, Vx, Fxt;           // overlap-save tiles along the rows axis (nxt = 1: one full-length transform), valid
+                              // stride-1 samples per tile, bin columns per plane = nxt * Fx
   int nd_cob, nd_Cog_pad;
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
@@ -163,7 +165,7 @@ struct fc_plan {
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
-  int exp_sleep, exp_prio, exp_pref;   // tuning knobs of the batch-sharing kernel (environment, read at plan creation)
+  int exp_sleep, exp_prio, exp_pref, exp_slot;   // tuning knobs of the batch-sharing kernel (environment, read at plan creation)
 };
 
 extern "C" {
@@ -509,10 +511,27 @@ static const fc::TileImpl* smallest_tile_at_least(int64_t n) {
 static int plan_nd(fc_plan* p) {
   const fc_desc& d = p->d;
   const int nd = p->nd;
-  // full-length transforms on the rows axis and (3-D) the middle axis
+  // rows axis: one full-length transform when the padded row fits the largest FFT, overlap-save tiles otherwise
+  // (the reference has no size limit: functional.py:66-70); middle axis (3-D): full-length transform
+  p->nxt = 1;
+  p->Vx = p->Lf[nd - 1];
   p->tx = smallest_tile_at_least(p->Sp[nd - 1]);
-  if (!p->tx) return fail(FC_ERR_UNSUPPORTED, "padded extent %d of the last axis exceeds the largest FFT (4096)", p->Sp[nd - 1]);
+  {
+    const char* env = getenv("FFTCONV_XTILE");       // testing knob: force x tiles of this length (where the kernel fits)
+    const int64_t kdx = p->kd[nd - 1];
+    int forced = env ? atoi(env) : 0;
+    if (forced && (!find_tile(forced) || find_tile(forced)->T < kdx)) forced = 0;
+    if (!p->tx || forced) {
+      const fc::TileImpl* t = forced ? find_tile(forced) : find_tile(kdx <= 1025 ? 2048 : 4096);
+      if (!t || t->T < kdx)
+        return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld along the last axis exceeds the largest FFT (4096)", (long long)kdx);
+      p->tx = t;
+      p->Vx = (int)(t->T - kdx + 1);
+      p->nxt = (int)((p->Lf[nd - 1] + p->Vx - 1) / p->Vx);
+    }
+  }
   p->Fx = p->tx->T / 2 + 1;
+  p->Fxt = p->nxt * p->Fx;
   p->tm = nullptr;
   if (nd == 3) {
     p->tm = smallest_tile_at_least(p->Sp[1]);
@@ -552,21 +571,22 @@ static int plan_nd(fc_plan* p) {
   p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * p->CB * best->lseqp * sizeof(fc::f2);
 
   const size_t B = (size_t)d.batch, Ci = (size_t)d.in_channels, Co = (size_t)d.out_channels;
-  const size_t Fx = (size_t)p->Fx;
+  const size_t Fx = (size_t)p->Fx;          // bin columns of the kernel spectrum (one x tile)
+  const size_t Fs = (size_t)p->Fxt;         // bin columns of the signal side (all x tiles)
   size_t ncol, a_sig, b_sig, a_w, b_w;
   if (nd == 2) {
     ncol = Fx;
-    a_sig = B * Ci * Fx * p->Sp[0];                       // S1[(b,ci)][fx][yp]
-    b_sig = B * Co * Fx * (size_t)p->out_sp[0];           // O1[(b,co)][fx][y_out]
+    a_sig = B * Ci * Fs * p->Sp[0];                       // S1[(b,ci)][xt,fx][yp]
+    b_sig = B * Co * Fs * (size_t)p->out_sp[0];           // O1[(b,co)][xt,fx][y_out]
     a_w = Co * p->Cig * Fx * (size_t)p->kd[0];            // S1w[(o,i)][fx][y<Kd]
     b_w = 0;
   } else {
     const size_t Ty = (size_t)p->tm->T;
     ncol = Fx * Ty;
-    a_sig = std::max(B * Ci * p->Sp[0] * Fx * p->Sp[1],            // S1[(b,ci)][zp][fx][yp]
-                     B * Co * Fx * Ty * (size_t)p->out_sp[0]);      // O2[(b,co)][fx][fy][z_out]
-    b_sig = std::max(B * Ci * Fx * Ty * p->Sp[0],                   // S2[(b,ci)][fx][fy][zp]
-                     B * Co * (size_t)p->out_sp[0] * Fx * (size_t)p->out_sp[1]);   // O1[(b,co)][z_out][fx][y_out]
+    a_sig = std::max(B * Ci * p->Sp[0] * Fs * p->Sp[1],            // S1[(b,ci)][zp][xt,fx][yp]
+                     B * Co * Fs * Ty * (size_t)p->out_sp[0]);      // O2[(b,co)][xt,fx][fy][z_out]
+    b_sig = std::max(B * Ci * Fs * Ty * p->Sp[0],                   // S2[(b,ci)][xt,fx][fy][zp]
+                     B * Co * (size_t)p->out_sp[0] * Fs * (size_t)p->out_sp[1]);   // O1[(b,co)][z_out][xt,fx][y_out]
     a_w = Co * p->Cig * (size_t)p->kd[0] * Fx * (size_t)p->kd[1];
     b_w = Co * p->Cig * Fx * Ty * (size_t)p->kd[0];
   }
@@ -652,6 +672,7 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
     p->exp_sleep = env_int("FFTCONV_EXP_SLEEP", 0);
     p->exp_prio = env_int("FFTCONV_EXP_PRIO", 0);
     p->exp_pref = env_int("FFTCONV_EXP_PREF", 0);
+    p->exp_slot = env_int("FFTCONV_EXP_SLOT", 0);
   }
 
   int rc;
@@ -775,7 +796,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
   layout[1] = p.ph; layout[2] = p.nseg; layout[3] = p.seg_taps;
   layout[4] = p.diag; layout[5] = p.bd_gs; layout[6] = p.wide; layout[7] = p.pers_nb;
   if (p.nd != 1) {   // N-d: the spectrum is laid out over the row / middle-axis transform lengths too
-    layout[1] = p.tx ? p.tx->T : 0; layout[2] = p.tm ? p.tm->T : 0; layout[3] = p.nd_cob;
+    layout[1] = p.tx ? p.tx->T : 0; layout[2] = p.tm ? p.tm->T : 0; layout[3] = p.nd_cob;   // (x tiles share one kernel spectrum)
     layout[4] = layout[5] = layout[6] = layout[7] = 0;
   }
   return FC_OK;
@@ -784,7 +805,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan) return 0;
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
-    const long long ncol = plan->nd == 2 ? plan->Fx : (long long)plan->Fx * plan->tm->T;
+    const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
   }
   if (plan->pers_nb) return (long long)plan->pers_items * 16;   // one record per wave (up to 16) of every work item
@@ -835,6 +856,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   r.kz = nd == 3 ? (int)p.d.kernel[0] : 1; r.dz = nd == 3 ? (int)p.d.dilation[0] : 1;
   r.NA = Co * p.Cig; r.NC = nd == 3 ? (int)p.kd[0] : 1; r.NY = (int)p.kd[nd - 2]; r.NYa = r.NY;
   r.SZ = r.kz; r.SY = r.ky; r.SX = r.kx; r.Fx = p.Fx;
+  r.nxt = 1; r.Vx = 0;                       // the kernel sits in the first x tile
   r.transposed = p.d.transposed; r.Cig = p.Cig; r.Cog = p.Cog;
   FC_HIP(p.tx->rows_r2c(r, st));
   const float norm = 1.0f / ((float)p.tx->T * (float)p.tile->T * (nd == 3 ? (float)p.tm->T : 1.0f));
@@ -888,7 +910,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)stamps;
     a.segmented = p.nseg > 1; a.pos_shift = 0;
-    a.exp_sleep = p.exp_sleep; a.exp_prio = p.exp_prio; a.exp_pref = p.exp_pref;
+    a.exp_sleep = p.exp_sleep; a.exp_prio = p.exp_prio; a.exp_pref = p.exp_pref; a.exp_slot = p.exp_slot;
     if (p.pers_nb) {
       for (int j = 0; j < p.nseg; ++j) {
         fc::Conv1dPersArgs pa;
@@ -935,6 +957,8 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1; r.transposed = 0; r.Cig = p.Cig; r.Cog = p.Cog;
   r.NA = B * Ci; r.NC = nd == 3 ? p.Sp[0] : 1; r.NY = p.Sp[nd - 2]; r.NYa = r.NY;
   r.SZ = nd == 3 ? (int)p.d.spatial[0] : 1; r.SY = (int)p.d.spatial[nd - 2]; r.SX = (int)p.d.spatial[nd - 1]; r.Fx = p.Fx;
+  r.nxt = p.nxt; r.Vx = p.Vx;
+  const int Fs = p.Fxt;                       // signal-side bin columns per plane (all x tiles)
   {
     const unsigned long long bytes = 4ull * (unsigned long long)B * Ci * r.SZ * r.SY * r.SX;
     r.src_bytes = bytes < 0xFFFFFFFFull ? (unsigned)bytes : 0u;
@@ -951,12 +975,13 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
 
   fc::RowsC2RArgs o{};
   o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;
-  o.NA = B * Co; o.Fx = p.Fx; o.Cout = Co;
+  o.NA = B * Co; o.Fx = p.Fx; o.Cout = Co; o.nxt = p.nxt; o.Vx = p.Vx;
+  f.wfx = p.Fx; f.wty = nd == 3 ? p.tm->T : 1; f.wncol = f.wfx * f.wty;
   o.NV = p.Lf[nd - 1]; o.stride = p.ostride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
   o.NY = (int)p.out_sp[nd - 2]; o.NYa = o.NY;
 
   if (nd == 2) {
-    f.src = wsA; f.dst = wsB; f.ncol = p.Fx;
+    f.src = wsA; f.dst = wsB; f.ncol = Fs;
     FC_HIP(p.tile->fusedc(p.CB, f, st));
     o.src = wsB; o.NC = 1;
     FC_HIP(p.tx->rows_c2r(o, st));
@@ -965,17 +990,17 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     fc::C2CArgs c{};
     c.scale = 1.f; c.store_mode = 0; c.twA = p.twm.twA; c.twB = p.twm.twB;
     // S1[(b,ci)][zp][fx][yp] -> S2[(b,ci)][fx][fy][zp]
-    c.src = wsA; c.dst = wsB; c.NA = B * Ci; c.NC = p.Fx; c.NB = Szp; c.NLEN = Syp;
-    c.sa = (long long)Szp * p.Fx * Syp; c.sb = (long long)p.Fx * Syp; c.sc = Syp;
-    c.ta = (long long)p.Fx * Ty * Szp; c.tc = (long long)Ty * Szp; c.tf = Szp;
+    c.src = wsA; c.dst = wsB; c.NA = B * Ci; c.NC = Fs; c.NB = Szp; c.NLEN = Syp;
+    c.sa = (long long)Szp * Fs * Syp; c.sb = (long long)Fs * Syp; c.sc = Syp;
+    c.ta = (long long)Fs * Ty * Szp; c.tc = (long long)Ty * Szp; c.tf = Szp;
     c.NV = 0; c.stride = 1;
     FC_HIP(p.tm->c2c_fwd(c, st));
-    f.src = wsB; f.dst = wsA; f.ncol = p.Fx * Ty;
+    f.src = wsB; f.dst = wsA; f.ncol = Fs * Ty;
     FC_HIP(p.tile->fusedc(p.CB, f, st));
     // O2[(b,co)][fx][fy][z_out] -> O1[(b,co)][z_out][fx][y_out]
-    c.src = wsA; c.dst = wsB; c.NA = B * Co; c.NC = p.Fx; c.NB = Lzo;
-    c.sa = (long long)p.Fx * Ty * Lzo; c.sc = (long long)Ty * Lzo; c.sb = Lzo;
-    c.ta = (long long)Lzo * p.Fx * Lyo; c.tb = (long long)p.Fx * Lyo; c.tc = Lyo;
+    c.src = wsA; c.dst = wsB; c.NA = B * Co; c.NC = Fs; c.NB = Lzo;
+    c.sa = (long long)Fs * Ty * Lzo; c.sc = (long long)Ty * Lzo; c.sb = Lzo;
+    c.ta = (long long)Lzo * Fs * Lyo; c.tb = (long long)Fs * Lyo; c.tc = Lyo;
     c.NV = p.Lf[1]; c.stride = p.ostride[1];
     FC_HIP(p.tm->c2c_inv(c, st));
     o.src = wsB; o.NC = Lzo;

@@ -125,6 +125,8 @@ struct RowsR2CArgs {
   int SZ, SY, SX;        // source extents (signal: unpadded sizes; kernel: taps)
   int Fx;                // T/2 + 1
   unsigned src_bytes;    // size of the source tensor when it fits 32-bit buffer offsets, else 0
+  int nxt, Vx;           // overlap-save tiles along x (rows longer than the largest FFT): tile xt holds the padded
+                         // positions [xt*Vx, xt*Vx + T); dst has nxt*Fx bin columns per plane (1, - for one tile)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -141,9 +143,11 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
   const int yb = id % nyb; id /= nyb;
+  const int xt = id % a.nxt; id /= a.nxt;
   const int c = id % a.NC;
   const int img = id / a.NC;
   const int y0 = yb * RB;
+  const int x0 = xt * a.Vx;              // padded position of this tile's first sample
 
   f2 v[P];
   {
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
       const unsigned ro1 = ok[1] ? (unsigned)((rows[1] - a.src) * 4) : 0xFFFFFFFFu;
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
-        const int xs = G::N2 * n1 + tseq - a.mx.pad;
+        const int xs = x0 + G::N2 * n1 + tseq - a.mx.pad;
         const bool in = (unsigned)xs < (unsigned)a.SX;
         v[n1].x = buf_load_f32(sg, (in && ok[0]) ? ro0 + (unsigned)xs * 4u : 0xFFFFFFFFu, 0);
         v[n1].y = buf_load_f32(sg, (in && ok[1]) ? ro1 + (unsigned)xs * 4u : 0xFFFFFFFFu, 0);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
       f2* col = lds + sq * LSEQP + tseq;
 #pragma unroll 1
       for (int n1 = 0; n1 < P; ++n1) {
-        const int xp = G::N2 * n1 + tseq;
+        const int xp = x0 + G::N2 * n1 + tseq;
         int xs = a.from_kernel ? tap_src(xp, a.dx, a.kx) : axis_src(a.mx, xp);
         if (a.from_kernel && a.transposed && xs >= 0) xs = a.SX - 1 - xs;
         const float v0 = (ok[0] && xs >= 0) ? rows[0][xs] : 0.f;
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
   __syncthreads();
   // unpack the two real spectra of every pair and store transposed: RB rows contiguous per bin
-  f2* out = a.dst + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+  f2* out = a.dst + (((size_t)img * a.NC + c) * a.nxt + xt) * a.Fx * a.NYa + y0;
   for (int idx = tid; idx < a.Fx * RB; idx += NT) {
     const int r = idx % RB, fx = idx / RB;
     if (y0 + r >= a.NY) continue;
@@ -336,6 +340,7 @@ struct RowsC2RArgs {
   const f2* twB;
   int NA, NC, NY, NYa, Fx, Cout;
   int NV, stride, Xo;    // valid stride-1 samples along x, decimation, output row length
+  int nxt, Vx;           // x tiles (see RowsR2CArgs): tile xt yields the stride-1 samples [xt*Vx, xt*Vx + Vx)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -352,9 +357,12 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   const int nyb = (a.NY + RB - 1) / RB;
   int id = blockIdx.x;
   const int yb = id % nyb; id /= nyb;
+  const int xt = id % a.nxt; id /= a.nxt;
   const int c = id % a.NC;
   const int img = id / a.NC;
   const int y0 = yb * RB;
+  const int x0 = xt * a.Vx;                    // first stride-1 sample of this tile
+  const int xlim = min(a.Vx, a.NV - x0);       // valid samples the tile contributes
   f2 wtw[P];
   passA_twiddle_fetch<G>(wtw, tseq, twA);      // requested first: lands while the spectra are loaded
   {
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
     // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
     // Four bins per thread are requested before any is consumed (the loop is latency-bound otherwise);
     // a row pair is one 16-byte load when it is whole and aligned.
-    const f2* in = a.src + ((size_t)img * a.NC + c) * a.Fx * a.NYa + y0;
+    const f2* in = a.src + (((size_t)img * a.NC + c) * a.nxt + xt) * a.Fx * a.NYa + y0;
     const int total = a.Fx * NSEQ;
     const bool pair16 = ((a.NYa | y0) & 1) == 0;
     constexpr int U = 4;
@@ -410,22 +418,24 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;
   const int nbase = (tseq >> G::LGS) + P * P * j;
   if (a.stride == 1) {
+    o0 += x0; o1 += x0;
     if (has1) {
 #pragma unroll
       for (int k = 0; k < P; ++k)
-        if (nbase + P * k < a.NV) { o0[nbase + P * k] = v[k].x + b; o1[nbase + P * k] = v[k].y + b; }
+        if (nbase + P * k < xlim) { o0[nbase + P * k] = v[k].x + b; o1[nbase + P * k] = v[k].y + b; }
     } else if (has0) {
 #pragma unroll
       for (int k = 0; k < P; ++k)
-        if (nbase + P * k < a.NV) o0[nbase + P * k] = v[k].x + b;
+        if (nbase + P * k < xlim) o0[nbase + P * k] = v[k].x + b;
     }
     return;
   }
 #pragma unroll
   for (int k = 0; k < P; ++k) {
     const int n = nbase + P * k;
-    const int idx = n / a.stride;
-    if (n < a.NV && idx * a.stride == n) {
+    const int t = x0 + n;
+    const int idx = t / a.stride;
+    if (n < xlim && idx * a.stride == t) {
       if (has0) o0[idx] = v[k].x + b;
       if (has1) o1[idx] = v[k].y + b;
     }
@@ -442,6 +452,9 @@ struct FusedCArgs {
   const f2* twB;
   int B, Cin, Cout, G, Cig, Cog, Cig_pad, Cog_pad, cob, n_ochunks;
   int ncol, NLEN;        // columns per image, valid input length (zero beyond)
+  int wfx, wty, wncol;   // kernel-spectrum column of signal column col: ((col / wty) % wfx) * wty + col % wty -- with x
+                         // tiles the signal has nxt * wfx bin columns that share the wfx columns of the kernel;
+                         // wncol = wfx * wty spectrum columns per (o, ip)
   int Kd, V, ntiles, Lfull, NVo, stride;
   int accumulate;
   unsigned long long* stamps;   // profiling hook: 8 timestamps per workgroup, else null
@@ -492,8 +505,9 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   f2* vout = a.accumulate ? lds + NSEQ * LSEQP : lds;
   const int n_ichunks = a.Cig_pad / CIB;
   const int t0 = tile * a.V;
-  const size_t wcol = (size_t)a.ncol * T;                          // f4 per (o, ip)
-  const f4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)col * T;
+  const size_t wcol = (size_t)a.wncol * T;                         // f4 per (o, ip)
+  const int wc = ((col / a.wty) % a.wfx) * a.wty + col % a.wty;
+  const f4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)wc * T;
 
   for (int ic = 0; ic < n_ichunks; ++ic) {
     {

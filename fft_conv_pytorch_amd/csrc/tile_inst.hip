@@ -77,7 +77,7 @@ hipError_t rows_r2c_dispatch(const RowsR2CArgs& a, hipStream_t st) {
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
-  const long long grid = (long long)a.NA * a.NC * nyb;
+  const long long grid = (long long)a.NA * a.NC * a.nxt * nyb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
   return hipGetLastError();
@@ -113,7 +113,7 @@ hipError_t rows_c2r_dispatch(const RowsC2RArgs& a, hipStream_t st) {
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
-  const long long grid = (long long)a.NA * a.NC * nyb;
+  const long long grid = (long long)a.NA * a.NC * a.nxt * nyb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
   return hipGetLastError();
@@ -182,11 +182,11 @@ constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_
 
 // batch-sharing kernel builds: PHASES (dilation as phases) x DIAG (depthwise blocks); the plain one keeps its
 // immediate offsets and is the only one the headline configuration runs
-template <int NB, bool PHASES, bool DIAG, bool SEG = false, int PREF = 0>
+template <int NB, bool PHASES, bool DIAG, bool SEG = false, int PREF = 0, bool SLOT = false, bool TWG = false>
 hipError_t launch_pers_variant(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   constexpr int NT = NB * 4 * GG::TS;
   const size_t lds = pers_lds_bytes(NB);
-  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PREF>;
+  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PREF, SLOT, TWG>;
   static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
@@ -206,15 +206,14 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
     if (ph) return launch_pers_variant<NB, true, false>(a, grid, st);
     if (dg) return launch_pers_variant<NB, false, true>(a, grid, st);
 #if FC_P == 32 && FC_S == 1
-    if constexpr (NB == 4) switch (a.c.exp_pref) {      // one bin pair per thread: the whole spectrum share fits in registers
-      case 4: return launch_pers_variant<NB, false, false, false, 4>(a, grid, st);
-      case 13: return launch_pers_variant<NB, false, false, false, 13>(a, grid, st);
-      case 22: return launch_pers_variant<NB, false, false, false, 22>(a, grid, st);
-      case 30: return launch_pers_variant<NB, false, false, false, 30>(a, grid, st);
-      case 40: return launch_pers_variant<NB, false, false, false, 40>(a, grid, st);
-      case 3: return launch_pers_variant<NB, false, false, false, 3>(a, grid, st);
-      case 2: return launch_pers_variant<NB, false, false, false, 2>(a, grid, st);
-      default: break;
+    // tuning builds of the headline geometry (FFTCONV_EXP_*): spectrum prefetch before the forward passes,
+    // ping-pong slots of the two half-workgroups
+    if constexpr (NB == 4) {
+      if (a.c.exp_slot == 2) return launch_pers_variant<NB, false, false, false, 0, true, true>(a, grid, st);
+      if (a.c.exp_slot == 3) return launch_pers_variant<NB, false, false, false, 0, false, true>(a, grid, st);
+      if (a.c.exp_slot) return launch_pers_variant<NB, false, false, false, 0, true>(a, grid, st);
+      if (a.c.exp_pref == 40) return launch_pers_variant<NB, false, false, false, 40>(a, grid, st);
+      if (a.c.exp_pref == 22) return launch_pers_variant<NB, false, false, false, 22>(a, grid, st);
     }
 #endif
     return launch_pers_variant<NB, false, false>(a, grid, st);

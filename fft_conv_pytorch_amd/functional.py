@@ -26,7 +26,9 @@ def _require_gpu_f32(name: str, t: Tensor):
             f"fft_conv_pytorch_amd: `{name}` is on {t.device}; this implementation runs on ROCm devices only "
             f"(no CPU fallback). Move the tensor to 'cuda'.")
     if t.dtype != torch.float32:
-        raise TypeError(f"fft_conv_pytorch_amd: `{name}` has dtype {t.dtype}; only torch.float32 is supported")
+        raise TypeError(f"fft_conv_pytorch_amd: `{name}` has dtype {t.dtype}; the kernels compute in float32 "
+                        f"(float16 / bfloat16 tensors are accepted when signal, kernel and bias share the dtype; "
+                        f"float64 is not supported)")
 
 
 class KernelSpectrum:
@@ -183,6 +185,24 @@ def fft_conv(
     return _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, None)
 
 
+_LOW_PRECISION = (torch.float16, torch.bfloat16)
+
+
+def _string_padding(padding: str, kernel: Tensor, stride, dilation, n: int):
+    """``padding='valid' | 'same'`` as in torch.nn.functional.conv{N}d (the reference rejects strings: a str is
+    Iterable for its to_ntuple).  Returns (symmetric padding per axis, leading output samples to
+    drop per axis): 'same' needs d*(k-1) padded samples per axis, split floor/ceil like torch; an odd total is
+    run with the larger half on both sides and the surplus leading output sample dropped."""
+    if padding == "valid":
+        return (0,) * n, (0,) * n
+    if padding != "same":
+        raise ValueError(f"invalid padding string {padding!r}; expected 'same' or 'valid'")
+    if any(s != 1 for s in to_ntuple(stride, n)):
+        raise ValueError("padding='same' is not supported for strided convolutions")
+    total = [d * (int(k) - 1) for d, k in zip(to_ntuple(dilation, n), kernel.shape[2:])]
+    return tuple(t - t // 2 for t in total), tuple(t % 2 for t in total)
+
+
 def _needs_grad(*tensors) -> bool:
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -190,6 +210,18 @@ def _needs_grad(*tensors) -> bool:
 def _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padding_mode, spectrum, plan=None):
     """Shared by the functional and the modules; ``spectrum`` is an optional cached kernel transform and
     ``plan`` the plan the caller already looked up (and validated) for exactly these arguments."""
+    if isinstance(padding, str) and signal.ndim >= 3:
+        n = signal.ndim - 2
+        pads, drop = _string_padding(padding, kernel, stride, dilation, n)
+        out = _fft_conv_impl(signal, kernel, bias, stride, pads, dilation, groups, padding_mode, spectrum, plan)
+        if any(drop):
+            out = out[(slice(None), slice(None)) + tuple(slice(d, None) for d in drop)]
+        return out
+    if signal.dtype in _LOW_PRECISION and kernel.dtype == signal.dtype and (bias is None or bias.dtype == signal.dtype):
+        # half-precision tensors in, half-precision tensor out; the arithmetic is the fp32 path (one cast pass each way)
+        out = _fft_conv_impl(signal.float(), kernel.float(), None if bias is None else bias.float(), stride, padding,
+                             dilation, groups, padding_mode, None, None)
+        return out.to(signal.dtype)
     if _needs_grad(signal, kernel, bias):
         from .autograd import FFTConvFunction        # backward built from the same kernels (row N1)
         n = signal.ndim - 2

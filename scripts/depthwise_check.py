@@ -36,7 +36,7 @@ for (B, C, L, K, pad) in [(8, 64, 65536, 1025, 0), (8, 256, 16384, 512, 100), (4
                           (3, 24, 5000, 33, 5), (1, 8, 100000, 257, 0)]:
     torch.manual_seed(C)
     x = torch.randn(B, C, L, device=dev)
-    m = FFTConv1d(C, C, K, groups=C, padding=pad).to(dev)
+    m = FFTConv1d(C, C, K, groups=C, padding=pad).to(dev).eval()
     with torch.no_grad():
         y = m(x)
         ref = rfft_dw(x, m.weight, m.bias, pad)

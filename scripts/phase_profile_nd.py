@@ -19,7 +19,7 @@ ap.add_argument("--k", type=int, default=31)
 args = ap.parse_args()
 dev = "cuda:0"
 cls = fca.FFTConv2d if args.nd == 2 else fca.FFTConv3d
-layer = cls(args.ch, args.ch, args.k).to(dev)
+layer = cls(args.ch, args.ch, args.k).to(dev).eval()
 x = torch.randn(args.batch, args.ch, *([args.size] * args.nd), device=dev)
 for _ in range(3):
     y = layer(x)

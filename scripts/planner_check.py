@@ -32,7 +32,7 @@ out = []
 for B, L, K in SHAPES:
     x = torch.randn(B, 8, L, device=dev)
     try:
-        layer = FFTConv1d(8, 8, K).to(dev)
+        layer = FFTConv1d(8, 8, K).to(dev).eval()
         with torch.no_grad():
             layer(x)
             tile = layer.__dict__["_spectrum_cache"][1].plan.tile

@@ -287,3 +287,123 @@ def test_tensor_on_a_non_current_device():
     assert x.grad.device == dev1 and w.grad.device == dev1
     with pytest.raises(ValueError, match="same device"):
         fft_conv(x, w.to("cuda:0"))
+
+
+# ----------------------------------------------------------------------------- rows longer than the largest FFT (N-d)
+def test_nd_rows_longer_than_4096():
+    """The reference has no size limit (functional.py:66-70).  The last axis of a 2-D / 3-D problem runs in
+    overlap-save tiles once its padded extent passes 4096 (round 1 raised NotImplementedError)."""
+    from fft_conv_pytorch_amd.functional import fft_conv, fft_conv_transpose
+    gen = torch.Generator().manual_seed(77)
+    cases = [
+        ((2, 3, 64, 8192), (4, 3, 5, 33), dict(padding=(2, 7), padding_mode="reflect")),
+        ((1, 2, 8192, 64), (3, 2, 9, 5), dict(stride=(2, 1))),                                  # long OUTER axis (already tiled)
+        ((1, 4, 6, 10, 5000), (4, 2, 3, 3, 17), dict(groups=2, padding=(1, 1, 8), dilation=(1, 2, 3))),
+        ((2, 2, 40, 4500), (2, 2, 3, 1200), dict(padding=(1, 100), padding_mode="circular")),     # 4096-point x tiles
+        ((1, 3, 33, 6000), (5, 3, 4, 9), dict(stride=(1, 3), padding=(0, 4), padding_mode="replicate")),
+    ]
+    for xs, ws, kw in cases:
+        x = torch.randn(*xs, generator=gen, dtype=torch.float64)
+        w = torch.randn(*ws, generator=gen, dtype=torch.float64) / math.sqrt(np.prod(ws[1:]))
+        b = torch.randn(ws[0], generator=gen, dtype=torch.float64)
+        nd = len(xs) - 2
+        mode = kw.get("padding_mode", "constant")
+        pad = kw.get("padding", 0)
+        pads = (pad,) * nd if isinstance(pad, int) else tuple(pad)
+        kwt = {k: v for k, v in kw.items() if k not in ("padding", "padding_mode")}
+        if mode == "constant":
+            want = getattr(F, f"conv{nd}d")(x, w, b, padding=pads, **kwt)
+        else:
+            flat = []
+            for p_ in reversed(pads):
+                flat += [p_, p_]
+            want = getattr(F, f"conv{nd}d")(F.pad(x, flat, mode=mode), w, b, **kwt)
+        got = fft_conv(x.float().to(DEV), w.float().to(DEV), b.float().to(DEV), **kw)
+        assert got.shape == want.shape
+        assert _rel(got, want) < REL_TOL, (xs, ws, kw, _rel(got, want))
+    # transposed, long rows
+    x = torch.randn(1, 3, 20, 2500, generator=gen, dtype=torch.float64)
+    w = torch.randn(3, 2, 3, 9, generator=gen, dtype=torch.float64) / 5
+    want = F.conv_transpose2d(x, w, stride=(1, 2), padding=(1, 3), output_padding=(0, 1))
+    got = fft_conv_transpose(x.float().to(DEV), w.float().to(DEV), stride=(1, 2), padding=(1, 3), output_padding=(0, 1))
+    assert got.shape == want.shape and _rel(got, want) < REL_TOL
+
+
+@pytest.mark.parametrize("xtile", [64, 256])
+def test_nd_forced_x_tiles_match_single_transform(xtile, monkeypatch):
+    """The same problems with and without x tiles (FFTCONV_XTILE forces tiles on rows that would fit one FFT):
+    2-D / 3-D, strides, padding modes, backward through the tiled plans."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(78 + xtile)
+    cases = [
+        ((2, 4, 30, 300), (6, 2, 5, 7), dict(groups=2, padding=(2, 3), stride=(1, 2))),
+        ((2, 3, 25, 500), (3, 3, 3, 31), dict(padding=(1, 15), padding_mode="reflect")),
+        ((1, 2, 7, 9, 400), (4, 2, 3, 2, 11), dict(dilation=(1, 1, 2), padding=(1, 0, 10), padding_mode="circular")),
+    ]
+    for xs, ws, kw in cases:
+        x = torch.randn(*xs, generator=gen).to(DEV).requires_grad_()
+        w = torch.randn(*ws, generator=gen).to(DEV).requires_grad_()
+        b = torch.randn(ws[0], generator=gen).to(DEV)
+        monkeypatch.delenv("FFTCONV_XTILE", raising=False)
+        _native.clear_plan_cache()
+        y0 = fft_conv(x, w, b, **kw)
+        gy = torch.randn(y0.shape, generator=gen).to(DEV)
+        gx0, gw0 = torch.autograd.grad(y0, (x, w), gy)
+        monkeypatch.setenv("FFTCONV_XTILE", str(xtile))
+        _native.clear_plan_cache()
+        y1 = fft_conv(x, w, b, **kw)
+        gx1, gw1 = torch.autograd.grad(y1, (x, w), gy)
+        monkeypatch.delenv("FFTCONV_XTILE", raising=False)
+        _native.clear_plan_cache()
+        assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 1e-5 and _rel(gw1, gw0) < 1e-5, (xs, kw)
+
+
+# ----------------------------------------------------------------------------- N4 supersets: padding strings, half precision
+def test_string_padding_and_half_precision_inputs():
+    """``padding='same' | 'valid'`` as torch's direct convolution takes them (the reference rejects strings), for
+    even and odd dilated extents, functional and module; float16 / bfloat16 tensors go through the fp32 kernels."""
+    import fft_conv_pytorch_amd as fca
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(91)
+    for xs, ws, dil, mode in [((2, 4, 301), (6, 4, 8), 1, "constant"), ((2, 4, 300), (6, 2, 5), 3, "constant"),
+                              ((1, 3, 40, 51), (5, 3, 4, 6), (1, 2), "constant"), ((2, 2, 9, 10, 11), (2, 2, 2, 3, 4), 1, "constant"),
+                              ((2, 3, 120), (3, 3, 6), 2, "reflect")]:
+        x = torch.randn(*xs, generator=gen).to(DEV)
+        w = torch.randn(*ws, generator=gen).to(DEV)
+        b = torch.randn(ws[0], generator=gen).to(DEV)
+        nd = len(xs) - 2
+        groups = xs[1] // ws[1]
+        conv = getattr(F, f"conv{nd}d")
+        for pad in ("same", "valid"):
+            if mode == "constant":
+                want = conv(x.double(), w.double(), b.double(), padding=pad, dilation=dil, groups=groups)
+            else:
+                layer = getattr(torch.nn, f"Conv{nd}d")(xs[1], ws[0], ws[2:], padding=pad, dilation=dil, groups=groups,
+                                                        padding_mode=mode).to(DEV).double()
+                with torch.no_grad():
+                    layer.weight.copy_(w.double())
+                    layer.bias.copy_(b.double())
+                want = layer(x.double()).detach()
+            got = fft_conv(x, w, b, padding=pad, dilation=dil, groups=groups, padding_mode=mode)
+            assert got.shape == want.shape, (xs, ws, pad, got.shape, want.shape)
+            assert _rel(got, want) < REL_TOL, (xs, ws, pad)
+    layer = fca.FFTConv2d(3, 5, (4, 3), padding="same", bias=True).to(DEV)
+    x = torch.randn(2, 3, 20, 21, device=DEV, requires_grad=True)
+    y = layer(x)
+    want = F.conv2d(x, layer.weight, layer.bias, padding="same")
+    assert y.shape == want.shape and _rel(y, want) < REL_TOL
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, (x, layer.weight), gy)
+    gx_r, gw_r = torch.autograd.grad(want, (x, layer.weight), gy)
+    assert _rel(gx, gx_r) < REL_TOL and _rel(gw, gw_r) < REL_TOL
+    for dt, tol in ((torch.bfloat16, 2e-2), (torch.float16, 3e-3)):
+        xh = torch.randn(2, 8, 3000, device=DEV).to(dt)
+        wh = (torch.randn(8, 8, 65, device=DEV) / 20).to(dt)
+        bh = torch.randn(8, device=DEV).to(dt)
+        yh = fft_conv(xh, wh, bh, padding=32)
+        assert yh.dtype == dt
+        want = F.conv1d(xh.double(), wh.double(), bh.double(), padding=32)
+        assert _rel(yh, want) < tol
+    with pytest.raises(TypeError, match="float64 is not supported"):
+        fft_conv(torch.zeros(1, 2, 16, device=DEV, dtype=torch.float64), torch.zeros(2, 2, 3, device=DEV, dtype=torch.float64))

@@ -48,7 +48,6 @@ struct Conv1dArgs {
   int pos_shift;         // kernel segment: its first tap sits this many samples into the (dilated) kernel
   int add_out;           // 1: y += result (later chunk launches of such a plan; bias went with the first)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
-  int exp_sleep, exp_prio, exp_pref, exp_slot;   // batch-sharing kernel tuning knobs (FFTCONV_EXP_SLEEP / _PRIO / _PREF), 0 = off
 };
 
 // Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with

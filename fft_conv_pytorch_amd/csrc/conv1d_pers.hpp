@@ -36,13 +36,8 @@ __device__ __forceinline__ void stamp_item(unsigned long long* buf, int item, in
   if (buf != nullptr && (threadIdx.x & 63) == 0)
     buf[((size_t)item * 16 + (threadIdx.x >> 6)) * 16 + slot] = __builtin_amdgcn_s_memrealtime();
 }
-// wave-uniform delay of about 64 * n cycles (tuning knob of the half-workgroup stagger)
-__device__ __forceinline__ void wave_sleep(int n) {
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-}
 
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false,
-          int PREF = 0, bool SLOT = false, bool TWG = false>
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   using G = Geo<P, S>;
   constexpr int T = G::T;
@@ -69,7 +64,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
-  const BufRsrc twAg = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));      // TWG: pass-A twiddles through L1 instead of LDS
   const size_t wgroup = (size_t)a.Cog_pad * (a.Cig_pad / 2) * (T / 2);   // float4 per group
 
   // ---- input samples of one item -> registers (unrolled buffer loads; border tiles get per-sample
@@ -134,83 +128,12 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
     // ------------------------------------------------ forward pass A
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
-    // Full prefetch (PREF): every spectrum value this thread contracts is requested now, so the L2 -> L1
-    // stream of the kernel spectrum runs beside the forward transforms instead of in front of the mix.
-    const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
-    const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
-    auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
-      const unsigned vo = (unsigned)(tid + m * NT) * 16u;
-      const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
-#pragma unroll
-      for (int p = 0; p < NPI; ++p) {
-        dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
-        dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
-      }
-    };
-    // PREF = 10 * (sets requested before pass A) + (sets requested between pass A and pass B); the rest of the
-    // BP * NPI sets goes out in front of the mix barrier.  0 = the two-set ring refilled inside the mix.
-    constexpr int PRE_A = PREF / 10, PRE_B = PREF % 10;
-    constexpr int NRING = (PREF && !DIAG) ? BP * NPI : RING;
-    static_assert(PRE_A + PRE_B <= BP * NPI, "cannot prefetch more sets than the mix has steps");
-    static_assert(!PREF || BP == 1, "full prefetch keeps BP * NPI sets of 32 registers: one bin pair per thread only");
-    f4 wr[DIAG ? 1 : NRING][2 * NPI];
-    if constexpr (PREF && !DIAG) {
-      static_for<0, PRE_A>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        issue(s / NPI, s % NPI, wr[s]);
-      });
-      if constexpr (PRE_A > 0) __builtin_amdgcn_sched_barrier(0);     // keep the requests up here
-    }
-    // Ping-pong slots (SLOT): the two waves of a SIMD (wave w and w + NT/128) do NOT overlap their LDS and
-    // VALU work when they run the same stage at the same time (measured: the forward passes take the SUM of
-    // the two), but a wave that only moves data through LDS and a partner that only issues butterflies run
-    // side by side at full speed (scripts/ubench/ubench_roles.hip: "LV").  So the transforms are cut at their
-    // VALU / LDS boundaries by workgroup barriers and the second half of the workgroup runs one stage behind
-    // the first: in every slot one half is in a VALU stage while the other is in an LDS stage.
-    const bool h1 = tid >= NT / 2;
-    auto slot_bar = [&](bool on) { if (SLOT && on) __builtin_amdgcn_s_barrier(); };
-    if (a.exp_sleep > 0 && h1) wave_sleep(a.exp_sleep);     // half-workgroup stagger (older tuning knob)
     // (act_in is wave-uniform and the two passes of a sequence only need wave-level ordering)
-    if constexpr (SLOT) {
-      int j = 0;
-      slot_bar(h1);
-      if (act_in) {                                                        // V: butterflies + twiddles
-        if constexpr (TWG) passA_compute_gl<G, -1>(v, tseq, twAg);
-        else passA_compute_lds<G, -1>(v, tseq, twl);
-      }
-      stamp_item(a.stamps, it, 2);
-      slot_bar(true);
-      if (act_in) {                                                        // L: row stores, row loads
-        passA_store<G>(v, zseq, tseq);
-        seq_sync<G>();
-        stamp_item(a.stamps, it, 3);
-        passB_load<G>(v, zseq, tseq);
-        seq_sync<G>();
-      }
-      slot_bar(true);
-      if (act_in) j = passB_compute<G, -1>(v, tseq, twB);                   // V: butterflies
-      slot_bar(true);
-      if (act_in) {                                                        // L: natural-order stores
-        const int k1 = tseq >> G::LGS;
-        f2* dst = zseq + G::nat(k1 + P * P * j);
-#pragma unroll
-        for (int k = 0; k < P; ++k) dst[P * k] = v[k];
-      }
-      slot_bar(!h1);
-    } else if (act_in) {
-      if constexpr (TWG) passA_fft_twiddle_store<G, -1>(v, zseq, tseq, twAg);
-      else if constexpr (PRE_A > 0) passA_fft_twiddle_store_lds_lowreg<G, -1>(v, zseq, tseq, twl);
-      else passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
+    if (act_in) {
+      passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
       stamp_item(a.stamps, it, 2);
       seq_sync<G>();
       stamp_item(a.stamps, it, 3);
-      if constexpr (PREF && !DIAG) {
-        static_for<PRE_A, PRE_A + PRE_B>([&](auto sc) {
-          constexpr int s = decltype(sc)::value;
-          issue(s / NPI, s % NPI, wr[s]);
-        });
-        if constexpr (PRE_B > 0) __builtin_amdgcn_sched_barrier(0);
-      }
       // ---------------------------------------------- forward pass B
       passB_load<G>(v, zseq, tseq);
       seq_sync<G>();
@@ -277,6 +200,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     // ------------------------------------------------ mix
     // The first two spectrum sets (and the self-paired bins' weights) do not depend on this item's
     // transforms: they are requested BEFORE the barrier and travel while the slower waves finish.
+    const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
+    const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
     // Self-paired bins 0 and T/2 (both spectra real there; wspec[.][0] = {Re H[0], Re H[T/2]}):
     // lane (batch b, output o, bin) of wave 0 owns one real output.
     const int sb_b = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;
@@ -289,19 +214,22 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     // spectrum pipeline: step = (bin pair m, output pair q); two named register sets (static
     // indices), both in flight: set A holds step s, set B step s+1, each is refilled with step s+2
     // right after it has been contracted
+    auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
+      const unsigned vo = (unsigned)(tid + m * NT) * 16u;
+      const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#pragma unroll
+      for (int p = 0; p < NPI; ++p) {
+        dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
+        dst[2 * p + 1] = buf_load_f32x4(wg, vo, sb + p * (T / 2) * 16);
+      }
+    };
     // RING register sets: step s lives in set s % RING; the first RING steps are requested here
     // (RING = 3 fits in 244 VGPRs at NB = 4 but measured no faster than 2: 37.4 vs 36.9 us at cfgA)
-    if constexpr (!PREF) {
-      static_for<0, NRING>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        if constexpr (s < BP * NPI) issue(s / NPI, s % NPI, wr[s]);
-      });
-    } else {
-      static_for<PRE_A + PRE_B, NRING>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
-        issue(s / NPI, s % NPI, wr[s]);
-      });
-    }
+    f4 wr[RING][2 * NPI];
+    static_for<0, RING>([&](auto sc) {
+      constexpr int s = decltype(sc)::value;
+      if constexpr (s < BP * NPI) issue(s / NPI, s % NPI, wr[s]);
+    });
     stamp_item(a.stamps, it, 4);
     __syncthreads();
     stamp_item(a.stamps, it, 5);
@@ -311,13 +239,10 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
         for (int p = 0; p < NPI; ++p) sbz[p] = zbuf[(sb_b * NPI + p) * G::LSEQ + G::nat(sb_f)];
       }
-      // PREF keeps every spectrum set of the thread in registers, so the batch items go through the
-      // contraction NBH at a time (their 2 * NBH * NPI bin values are what else has to fit)
-      constexpr int NBH = PREF ? (NB >= 2 ? 2 : 1) : NB;
-      f2 xe[NBH][NPI], xo[NBH][NPI];       // 2*X of the even / odd channel of every pair
-      auto contract = [&](int f, int fm, int q, int b0, const f4 (&wc)[2 * NPI]) {
+      f2 xe[NB][NPI], xo[NB][NPI];       // 2*X of the even / odd channel of every pair
+      auto contract = [&](int f, int fm, int q, const f4 (&wc)[2 * NPI]) {
 #pragma unroll
-        for (int b = 0; b < NBH; ++b) {
+        for (int b = 0; b < NB; ++b) {
           f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
@@ -325,8 +250,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
             cmac(ya, xe[b][p], ha.xy); cmac(ya, xo[b][p], ha.zw);
             cmac(yb, xe[b][p], hb.xy); cmac(yb, xo[b][p], hb.zw);
           }
-          if (f != 0 && b0 + b < wi.nbc) {
-            f2* zb = zbuf + ((b0 + b) * NPI + q) * G::LSEQ;
+          if (f != 0 && b < wi.nbc) {
+            f2* zb = zbuf + (b * NPI + q) * G::LSEQ;
             zb[G::nat(f)] = add_pi(ya, yb);
             zb[G::nat(fm)] = conj_add_iconj(ya, yb);
           }
@@ -336,37 +261,34 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         constexpr int m = decltype(mc)::value;
         const int f = tid + m * NT;
         const int fm = (T - f) & (T - 1);
-        static_for<0, NB / NBH>([&](auto rc) {
-          constexpr int b0 = decltype(rc)::value * NBH;
-          {
-            // all 2*NBH*NPI bin reads are requested first (plain ds_read_b64), then combined
-            const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
-            static_for<0, NBH>([&](auto bc) {
-              constexpr int b = decltype(bc)::value;
-              const unsigned bf = af + (b0 + b) * NPI * G::LSEQ * 8, bg = ag + (b0 + b) * NPI * G::LSEQ * 8;
-              static_for<0, NPI>([&](auto pc) {
-                constexpr int p = decltype(pc)::value;
-                xe[b][p] = lds_rd<p * G::LSEQ * 8>(bf);
-                xo[b][p] = lds_rd<p * G::LSEQ * 8>(bg);
-              });
+        {
+          // all 2*NB*NPI bin reads are requested first (plain ds_read_b64), then combined
+          const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
+          static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const unsigned bf = af + b * NPI * G::LSEQ * 8, bg = ag + b * NPI * G::LSEQ * 8;
+            static_for<0, NPI>([&](auto pc) {
+              constexpr int p = decltype(pc)::value;
+              xe[b][p] = lds_rd<p * G::LSEQ * 8>(bf);
+              xo[b][p] = lds_rd<p * G::LSEQ * 8>(bg);
             });
-#pragma unroll
-            for (int b = 0; b < NBH; ++b) { lds_arrive(xe[b]); lds_arrive(xo[b]); }
-#pragma unroll
-            for (int b = 0; b < NBH; ++b)
-#pragma unroll
-              for (int p = 0; p < NPI; ++p) {
-                const f2 zf = xe[b][p], zg = xo[b][p];
-                xe[b][p] = add_conj(zf, zg);
-                xo[b][p] = sub_conj_divi(zf, zg);
-              }
-          }
-          static_for<0, NPI>([&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            constexpr int s = m * NPI + q;               // this step; its set is refilled with step s + RING
-            contract(f, fm, q, b0, wr[s % NRING]);
-            if constexpr (s + NRING < BP * NPI) issue((s + NRING) / NPI, (s + NRING) % NPI, wr[s % NRING]);
           });
+#pragma unroll
+          for (int b = 0; b < NB; ++b) { lds_arrive(xe[b]); lds_arrive(xo[b]); }
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int p = 0; p < NPI; ++p) {
+              const f2 zf = xe[b][p], zg = xo[b][p];
+              xe[b][p] = add_conj(zf, zg);
+              xo[b][p] = sub_conj_divi(zf, zg);
+            }
+        }
+        static_for<0, NPI>([&](auto qc) {
+          constexpr int q = decltype(qc)::value;
+          constexpr int s = m * NPI + q;               // this step; its set is refilled with step s + RING
+          contract(f, fm, q, wr[s % RING]);
+          if constexpr (s + RING < BP * NPI) issue((s + RING) / NPI, (s + RING) % NPI, wr[s % RING]);
         });
       });
       if (sb_act) {
@@ -385,43 +307,18 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     __syncthreads();
     stamp_item(a.stamps, it, 7);
     // the next item's samples travel from HBM while this item's inverse passes run
-    slot_bar(h1);
     if (more) fetch(wnext, vnext);
-    if (a.exp_sleep > 0 && h1) wave_sleep(a.exp_sleep);
-    // ------------------------------------------------ inverse passes A', B' + store
-    int j = 0;
-    if constexpr (SLOT) {
-      if (act_in) {                                                        // L: natural-order loads
-        nat_load<G>(v, zseq, tseq);
-        seq_sync<G>();
-      }
-      slot_bar(true);
-      if (act_in) {                                                        // V
-        if constexpr (TWG) passA_compute_gl<G, +1>(v, tseq, twAg);
-        else passA_compute_lds<G, +1>(v, tseq, twl);
-      }
-      stamp_item(a.stamps, it, 8);
-      slot_bar(true);
-      if (act_in) {                                                        // L: row stores, row loads
-        passA_store<G>(v, zseq, tseq);
-        seq_sync<G>();
-        stamp_item(a.stamps, it, 9);
-        passB_load<G>(v, zseq, tseq);
-      }
-      slot_bar(true);
-      if (act_in) j = passB_compute<G, +1>(v, tseq, twB);                   // V (+ the global stores below)
-    } else if (act_in) {
+    // ------------------------------------------------ inverse pass A'
+    if (act_in) {
       nat_load<G>(v, zseq, tseq);
       seq_sync<G>();
-      if constexpr (TWG) passA_fft_twiddle_store<G, +1>(v, zseq, tseq, twAg);
-      else passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
+      passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
       stamp_item(a.stamps, it, 8);
       seq_sync<G>();
       stamp_item(a.stamps, it, 9);
+      // ---------------------------------------------- inverse pass B' + store
       passB_load<G>(v, zseq, tseq);
-      j = passB_compute<G, +1>(v, tseq, twB);
-    }
-    if (act_in) {
+      const int j = passB_compute<G, +1>(v, tseq, twB);
       const int o1 = tseq >> G::LGS;
       const int vb = a.slot_tiles ? wi.b0 : wi.b0 + nb;
       const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
@@ -458,15 +355,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           if (nbase + P * k < limit) { y0[ystep * k] = v[k].x + bias0; y1[ystep * k] = v[k].y + bias1; }
       }
     }
-    slot_bar(!h1);
     stamp_item(a.stamps, it, 10);
     if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); }
     seq_sync<G>();     // this wave's sequences are free again (the mix barriers order the other waves)
   };
 
-  // static priority of one half of the workgroup (tuning knob): 1 = first half, 2 = second half
-  if (a.exp_prio == 1 && tid < NT / 2) __builtin_amdgcn_s_setprio(1);
-  if (a.exp_prio == 2 && tid >= NT / 2) __builtin_amdgcn_s_setprio(1);
   const int it0 = blockIdx.x, it1 = blockIdx.x + gridDim.x;
   const bool two = it1 < pa.n_items;
   const WorkItem w0 = pa.items[it0];

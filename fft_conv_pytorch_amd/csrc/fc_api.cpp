@@ -165,7 +165,6 @@ struct fc_plan {
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   fc::WorkItem* d_items;
-  int exp_sleep, exp_prio, exp_pref, exp_slot;   // tuning knobs of the batch-sharing kernel (environment, read at plan creation)
 };
 
 extern "C" {
@@ -667,13 +666,6 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
     }
   }
   set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
-  {
-    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    p->exp_sleep = env_int("FFTCONV_EXP_SLEEP", 0);
-    p->exp_prio = env_int("FFTCONV_EXP_PRIO", 0);
-    p->exp_pref = env_int("FFTCONV_EXP_PREF", 0);
-    p->exp_slot = env_int("FFTCONV_EXP_SLOT", 0);
-  }
 
   int rc;
   if (d.ndim == 1) rc = plan_1d(p);
@@ -910,7 +902,6 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)stamps;
     a.segmented = p.nseg > 1; a.pos_shift = 0;
-    a.exp_sleep = p.exp_sleep; a.exp_prio = p.exp_prio; a.exp_pref = p.exp_pref; a.exp_slot = p.exp_slot;
     if (p.pers_nb) {
       for (int j = 0; j < p.nseg; ++j) {
         fc::Conv1dPersArgs pa;

@@ -289,46 +289,6 @@ __device__ __forceinline__ void passA_fft_twiddle_store_lds(f2 (&v)[G::P], f2* _
   for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
 }
 
-// Pass A in two parts for the ping-pong schedule of the batch-sharing kernel: butterflies + twiddles stay in
-// registers (VALU stage), the row stores go out separately (LDS stage).
-template <class G, int DIR>
-__device__ __forceinline__ void passA_compute_lds(f2 (&v)[G::P], int n2, const f2* __restrict__ twl) {
-  fft_regs<G::P, DIR>(v);
-  // the table is read in quarters: at most P/4 twiddle registers live beside the data and whatever the caller holds
-  constexpr int Q = G::P / 4;
-  const unsigned addr = lds_off(twl + n2);
-  static_for<0, 4>([&](auto hc) {
-    constexpr int h = decltype(hc)::value;
-    f2 w[Q];
-    static_for<0, Q>([&](auto ic) {
-      constexpr int k1 = h * Q + decltype(ic)::value;
-      w[decltype(ic)::value] = lds_rd<k1 * G::N2 * 8>(addr);
-    });
-    lds_arrive(w);
-#pragma unroll
-    for (int i = (h == 0 ? 1 : 0); i < Q; ++i) {
-      const int k1 = h * Q + i;
-      v[k1] = (DIR > 0) ? cmulc(v[k1], w[i]) : cmul(v[k1], w[i]);
-    }
-  });
-}
-// same with the twiddles requested from the global table (L1-resident, 8 KiB at T = 1024) before the butterflies:
-// the VALU stage then touches no LDS at all, so the partner wave's LDS burst cannot hold it up
-template <class G, int DIR>
-__device__ __forceinline__ void passA_compute_gl(f2 (&v)[G::P], int n2, BufRsrc twA) {
-  f2 w[G::P];
-  passA_twiddle_fetch<G>(w, n2, twA);
-  __builtin_amdgcn_sched_barrier(0);
-  fft_regs<G::P, DIR>(v);
-#pragma unroll
-  for (int k1 = 1; k1 < G::P; ++k1) v[k1] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
-}
-template <class G>
-__device__ __forceinline__ void passA_store(const f2 (&v)[G::P], f2* __restrict__ lseq, int n2) {
-#pragma unroll
-  for (int k1 = 0; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = v[k1];
-}
-
 // same, with the table read in two halves (half the twiddle registers live at a time): for kernels that
 // carry many accumulators across the transform
 template <class G, int DIR>

@@ -182,11 +182,11 @@ constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_
 
 // batch-sharing kernel builds: PHASES (dilation as phases) x DIAG (depthwise blocks); the plain one keeps its
 // immediate offsets and is the only one the headline configuration runs
-template <int NB, bool PHASES, bool DIAG, bool SEG = false, int PREF = 0, bool SLOT = false, bool TWG = false>
+template <int NB, bool PHASES, bool DIAG, bool SEG = false>
 hipError_t launch_pers_variant(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   constexpr int NT = NB * 4 * GG::TS;
   const size_t lds = pers_lds_bytes(NB);
-  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PREF, SLOT, TWG>;
+  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG>;
   static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
@@ -205,17 +205,6 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
     if (ph && dg) return launch_pers_variant<NB, true, true>(a, grid, st);
     if (ph) return launch_pers_variant<NB, true, false>(a, grid, st);
     if (dg) return launch_pers_variant<NB, false, true>(a, grid, st);
-#if FC_P == 32 && FC_S == 1
-    // tuning builds of the headline geometry (FFTCONV_EXP_*): spectrum prefetch before the forward passes,
-    // ping-pong slots of the two half-workgroups
-    if constexpr (NB == 4) {
-      if (a.c.exp_slot == 2) return launch_pers_variant<NB, false, false, false, 0, true, true>(a, grid, st);
-      if (a.c.exp_slot == 3) return launch_pers_variant<NB, false, false, false, 0, false, true>(a, grid, st);
-      if (a.c.exp_slot) return launch_pers_variant<NB, false, false, false, 0, true>(a, grid, st);
-      if (a.c.exp_pref == 40) return launch_pers_variant<NB, false, false, false, 40>(a, grid, st);
-      if (a.c.exp_pref == 22) return launch_pers_variant<NB, false, false, false, 22>(a, grid, st);
-    }
-#endif
     return launch_pers_variant<NB, false, false>(a, grid, st);
   }
 }

@@ -16,7 +16,7 @@ run() {  # name, timeout, cmd...
   echo "rc=$rc"; tail -n 4 "$OUT/$name.log"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping"; exit 1; fi
 }
-BENCH="python3 $ROOTDIR/bench.py --steps 100 --warmup 10 --no-cpu-baseline $*"
+BENCH="python3 $ROOTDIR/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-end-to-end $*"
 run ${TAG}_trace 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/${TAG}_trace" -- $BENCH
 i=0
 for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_WAIT_ANY" \

@@ -110,6 +110,31 @@ __global__ __launch_bounds__(256, 1) void kp(const f2* __restrict__ in, f2* __re
   if ((tid & 63) == 0) cyc[(size_t)blockIdx.x * 8 + tid / 64] = t1 - t0;
 }
 
+// 'BB' with the repetitions written out RU times (straight-line code as in the product kernel, which executes every
+// instruction once per work item) inside an outer loop: tests whether instruction supply limits such a stream.
+template <int RU>
+__global__ __launch_bounds__(512, 2) void ku(const f2* __restrict__ in, f2* __restrict__ out, unsigned long long* cyc, int R) {
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  const int tid = threadIdx.x;
+  f2 v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = in[(size_t)i * 1024 + tid];
+  f2* seq = lds + (tid / 32) * (32 * 33);
+  const int n2 = tid % 32;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int r = 0; r < R; r += RU) {
+#pragma unroll
+    for (int u = 0; u < RU; ++u) { do_valu(v); do_lds(v, seq, n2); }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  f2 acc = v[0];
+#pragma unroll
+  for (int i = 1; i < 32; ++i) acc = acc + v[i];
+  out[(size_t)blockIdx.x * 512 + tid] = acc;
+  if ((tid & 63) == 0) cyc[(size_t)blockIdx.x * 8 + tid / 64] = t1 - t0;
+}
+
 __global__ __launch_bounds__(512, 2) void k(const f2* __restrict__ in, f2* __restrict__ out, unsigned long long* cyc, int R, int role0, int role1,
                                             int prio) {
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
@@ -162,6 +187,20 @@ int main() {
       std::sort(h0.begin(), h0.end()); std::sort(h1.begin(), h1.end());
       printf("roles %s prio %d : half0 %6.0f cycles/rep   half1 %6.0f cycles/rep\n", c, prio, (double)h0[h0.size() / 2] / R, (double)h1[h1.size() / 2] / R);
     }
+  auto run_u = [&](auto kern, int ru) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    kern<<<256, 512, lds>>>(in, out, cyc, R);
+    kern<<<256, 512, lds>>>(in, out, cyc, R);
+    hipDeviceSynchronize();
+    std::vector<unsigned long long> hc(256 * 8);
+    hipMemcpy(hc.data(), cyc, hc.size() * 8, hipMemcpyDeviceToHost);
+    std::vector<unsigned long long> h0, h1;
+    for (int b = 0; b < 256; ++b)
+      for (int w = 0; w < 8; ++w) (w < 4 ? h0 : h1).push_back(hc[b * 8 + w]);
+    std::sort(h0.begin(), h0.end()); std::sort(h1.begin(), h1.end());
+    printf("BB, body written out %2d times: half0 %6.0f cycles/rep   half1 %6.0f cycles/rep\n", ru, (double)h0[h0.size() / 2] / R, (double)h1[h1.size() / 2] / R);
+  };
+  run_u(ku<1>, 1); run_u(ku<4>, 4); run_u(ku<16>, 16); run_u(ku<32>, 32); run_u(ku<64>, 64);
   {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     kp<<<256, 256, lds>>>(in, out, cyc, R);

@@ -79,7 +79,7 @@ def dominant_kernel_name(plan):
     tile, ph, nseg, seg_taps, diag, bd_gs, wide, pers_nb = plan.layout
     if plan.key[0] != 1:
         return "fusedc_kernel"
-    geo = {64: (8, 1), 256: (16, 1), 512: (16, 2), 1024: (32, 1), 2048: (32, 2), 4096: (32, 4)}.get(tile)
+    geo = {64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (32, 1), 2048: (32, 2), 4096: (32, 4)}.get(tile)
     if geo is None:
         return None
     if wide:

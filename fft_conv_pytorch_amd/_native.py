@@ -141,10 +141,10 @@ class Plan:
 
     def __init__(self, key: Tuple, device_index: int = 0):
         (ndim, batch, cin, cout, groups, spatial, kernel, stride, padding, dilation, mode, has_bias, tile_hint,
-         transposed, output_padding) = key
+         transposed, output_padding, dtype_code) = key
         lib = load_library()
         d = FcDesc()
-        d.ndim, d.dtype = ndim, 0
+        d.ndim, d.dtype = ndim, dtype_code
         d.batch, d.in_channels, d.out_channels, d.groups = batch, cin, cout, groups
         for i in range(3):
             d.spatial[i] = spatial[i] if i < ndim else 1
@@ -160,6 +160,8 @@ class Plan:
             _raise(lib, st)
         self._lib, self._h, self.key = lib, handle, key
         self.device_index = int(device_index)
+        import torch
+        self.dtype = torch.float64 if dtype_code == 1 else torch.float32
         out = (ctypes.c_int64 * 3)()
         lib.fc_output_shape(handle, ctypes.byref(out))
         self.out_spatial = tuple(int(out[i]) for i in range(ndim))

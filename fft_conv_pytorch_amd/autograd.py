@@ -9,7 +9,8 @@ autograd, so the three gradients are expressed as convolutions the native librar
                                               accumulated on chip); otherwise ``fc_forward`` with the roles of
                                               batch and channels swapped: signal' = X^T (Cin/g, B, *S), kernel' =
                                               dY^T (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;
-                                              long 1-D rows are cut into chunks that ride the group axis
+                                              all channel groups ride the group axis of that one call, long 1-D
+                                              rows are cut into chunks that ride it too
     db = sum of dY over batch and space    -> a plain reduction
 
 torch is used for data movement only (transposes, unfold views, the final chunk sum and db).
@@ -52,51 +53,58 @@ def _grad_input(grad: Tensor, weight: Tensor, in_spatial, stride, padding, dilat
     return torch.autograd.grad(padded, probe, dx)[0]
 
 
-def _grad_weight_group(x: Tensor, grad: Tensor, ksize, stride, padding, dilation, padding_mode) -> Tensor:
-    """dW of one channel group.  x: (B, Ci, *S), grad: (B, Co, *Lout) -> (Co, Ci, *k)."""
+def _grad_weight_plans(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
+    """dW through forward plans with the roles of batch and channels swapped, ALL channel groups in one call
+    (they ride the group axis of the swapped convolution).  x: (B, Cin, *S), grad: (B, Cout, *Lout) -> (Cout, Cin/g, *k)."""
     n = x.ndim - 2
-    b = x.shape[0]
-    kext = [(grad.shape[2 + i] - 1) * stride[i] + 1 for i in range(n)]
+    b, g = x.shape[0], groups
+    cog, cig, ksize = wshape[0] // groups, wshape[1], tuple(wshape[2:])
+    sp, lo = tuple(x.shape[2:]), tuple(grad.shape[2:])
+    kext = [(lo[i] - 1) * stride[i] + 1 for i in range(n)]
     kd0 = (ksize[0] - 1) * dilation[0] + 1
     # one overlap-save tile must hold kernel' (extent kext) plus the kd - 1 further samples that give the
     # k taps of dW; a longer gradient would leave the tile (almost) no valid window (V = T - kext + 1)
     max_ext = max(_DW_TILE - kd0 + 1, _DW_TILE // 4)
     if n == 1 and kext[0] > max_ext:
         # Long rows: kernel' (the gradient) is cut into chunks of C taps; chunk j only meets the signal
-        # window [j*C*s - p, j*C*s - p + (C-1)*s + 1 + Kd - 1).  Chunks ride the group axis.
+        # window [j*C*s - p, j*C*s - p + (C-1)*s + 1 + Kd - 1).  Chunks (and channel groups) ride the group axis.
         s, p, d = stride[0], padding[0], dilation[0]
         kd = kd0
         c_taps = max(1, (max_ext - 1) // s + 1)
-        lout = grad.shape[2]
+        lout = lo[0]
         nchunk = (lout + c_taps - 1) // c_taps
         seg = (c_taps - 1) * s + kd                                  # signal samples one chunk needs
         # one padded copy of each operand, then one gather through an overlapping strided view
         need = (nchunk - 1) * c_taps * s + seg
         if padding_mode == "constant" or p == 0:
-            xp = F.pad(x, [p, max(0, need - x.shape[-1] - p)])       # (B, Ci, >= need)
+            xp = F.pad(x, [p, max(0, need - x.shape[-1] - p)])       # (B, Cin, >= need)
         else:
             xp = F.pad(x, [p, p], mode=padding_mode)
             if xp.shape[-1] < need:
                 xp = F.pad(xp, [0, need - xp.shape[-1]])
+        xp = xp.contiguous()
         sb, sc, sl = xp.stride()
-        sig = xp.as_strided((x.shape[1], nchunk, b, seg), (sc, c_taps * s * sl, sb, sl)).reshape(x.shape[1], nchunk * b, seg)
-        gp = F.pad(grad, [0, nchunk * c_taps - lout])                # (B, Co, nchunk*C)
+        # signal' (Cig, [g, chunk, b], seg): batch' = the input channel inside its group, channels' = (group, chunk, batch)
+        sig = xp.as_strided((cig, g, nchunk, b, seg), (sc, cig * sc, c_taps * s * sl, sb, sl)).reshape(cig, g * nchunk * b, seg)
+        gp = F.pad(grad, [0, nchunk * c_taps - lout]).contiguous()   # (B, Cout, nchunk*C)
         gb, gc, gl = gp.stride()
-        ker = gp.as_strided((nchunk, grad.shape[1], b, c_taps), (c_taps * gl, gc, gb, gl)).reshape(nchunk * grad.shape[1], b, c_taps)
-        part = F_.fft_conv(sig, ker.contiguous(), None, stride=d, padding=0, dilation=s, groups=nchunk)
-        part = part.reshape(x.shape[1], nchunk, grad.shape[1], -1).sum(dim=1)      # (Ci, Co, >=k)
-        return part[..., : ksize[0]].permute(1, 0, 2).contiguous()
-    xt = x.transpose(0, 1).contiguous()          # (Ci, B, *S)   : batch' = Ci, channels' = B
-    gt = grad.transpose(0, 1).contiguous()       # (Co, B, *Lout): out' = Co,  in' = B
-    out = F_.fft_conv(xt, gt, None, stride=dilation, padding=padding, dilation=stride, groups=1,
-                      padding_mode=padding_mode)                    # (Ci, Co, >= k per axis)
+        # kernel' ([g, chunk, o], b, C): out' = (group, chunk, output channel inside the group), in' = batch
+        ker = gp.as_strided((g, nchunk, cog, b, c_taps), (cog * gc, c_taps * gl, gc, gb, gl)).reshape(g * nchunk * cog, b, c_taps)
+        part = F_.fft_conv(sig, ker.contiguous(), None, stride=d, padding=0, dilation=s, groups=g * nchunk)
+        part = part.reshape(cig, g, nchunk, cog, -1).sum(dim=2)      # (Cig, g, Cog, >= k)
+        return part[..., : ksize[0]].permute(1, 2, 0, 3).reshape(g * cog, cig, ksize[0]).contiguous()
+    # signal' (Cig, [g, b], *S), kernel' ([g, o], b, *Lout), groups' = g
+    xt = x.reshape((b, g, cig) + sp).permute((2, 1, 0) + tuple(range(3, 3 + n))).reshape((cig, g * b) + sp).contiguous()
+    gt = grad.reshape((b, g, cog) + lo).permute((1, 2, 0) + tuple(range(3, 3 + n))).reshape((g * cog, b) + lo).contiguous()
+    out = F_.fft_conv(xt, gt, None, stride=dilation, padding=padding, dilation=stride, groups=g,
+                      padding_mode=padding_mode)                    # (Cig, g*Cog, >= k per axis)
     index = (slice(None), slice(None)) + tuple(slice(0, k) for k in ksize)
-    return out[index].transpose(0, 1).contiguous()
+    return out[index].transpose(0, 1).contiguous()                  # (g*Cog, Cig, *k)
 
 
 def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode):
     """dW by ``fc_wgrad1d`` (cross-spectra accumulated on chip over batch and row); None when not covered."""
-    if x.ndim != 3:
+    if x.ndim != 3 or x.dtype != torch.float32:      # (float64 runs the direct kernel: dW through forward plans)
         return None
     from . import _native
     desc = _native.conv_desc(1, x.shape[0], x.shape[1], wshape[0], groups, (x.shape[2],), (wshape[2],), stride, padding,
@@ -120,13 +128,7 @@ def _grad_weight(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, gro
     native = _grad_weight_native(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
     if native is not None:
         return native
-    cout, cig = wshape[0], wshape[1]
-    cog = cout // groups
-    parts = []
-    for g in range(groups):
-        parts.append(_grad_weight_group(x[:, g * cig:(g + 1) * cig], grad[:, g * cog:(g + 1) * cog],
-                                        tuple(wshape[2:]), stride, padding, dilation, padding_mode))
-    return parts[0] if groups == 1 else torch.cat(parts, dim=0)
+    return _grad_weight_plans(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
 
 
 class FFTConvFunction(torch.autograd.Function):

@@ -16,6 +16,7 @@
 #include <string>
 #include <vector>
 
+#include "direct_f64.h"
 #include "fc_internal.h"
 #include "fftconv_amd.h"
 
@@ -40,8 +41,8 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 const fc::TileImpl* const* all_tiles(int* n) {
-  static const fc::TileImpl* tiles[] = {fc::get_tile_P8_S1(),  fc::get_tile_P16_S1(), fc::get_tile_P16_S2(),
-                                        fc::get_tile_P32_S1(), fc::get_tile_P32_S2(), fc::get_tile_P32_S4()};
+  static const fc::TileImpl* tiles[] = {fc::get_tile_P8_S1(),  fc::get_tile_P8_S2(),  fc::get_tile_P16_S1(), fc::get_tile_P16_S2(),
+                                        fc::get_tile_P32_S1(), fc::get_tile_P32_S2(), fc::get_tile_P32_S4()};   // T = 64 .. 4096
   *n = (int)(sizeof tiles / sizeof tiles[0]);
   return tiles;
 }
@@ -604,7 +605,7 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   *out_plan = nullptr;
   const fc_desc& d = *desc;
   if (d.ndim < 1 || d.ndim > 3) return fail(FC_ERR_INVALID, "ndim must be 1, 2 or 3 (got %d)", d.ndim);
-  if (d.dtype != FC_F32) return fail(FC_ERR_UNSUPPORTED, "only float32 is supported");
+  if (d.dtype != FC_F32 && d.dtype != FC_F64) return fail(FC_ERR_UNSUPPORTED, "dtype must be FC_F32 or FC_F64");
   if (d.batch < 1 || d.in_channels < 1 || d.out_channels < 1 || d.groups < 1)
     return fail(FC_ERR_INVALID, "batch, channels and groups must be positive");
   if (d.in_channels % d.groups || d.out_channels % d.groups)
@@ -668,7 +669,15 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   set_channel_layout(p, (int)d.groups, (int)(d.in_channels / d.groups), (int)(d.out_channels / d.groups));
 
   int rc;
-  if (d.ndim == 1) rc = plan_1d(p);
+  if (d.dtype == FC_F64) {
+    // float64: direct time-domain kernel (direct_f64.hip); the "kernel spectrum" is the weight tensor itself
+    size_t nw = (size_t)(d.transposed ? d.in_channels : d.out_channels) * (size_t)((d.transposed ? d.out_channels : d.in_channels) / d.groups);
+    for (int i = 0; i < d.ndim; ++i) nw *= (size_t)d.kernel[i];
+    p->spectrum_bytes = nw * sizeof(double);
+    p->workspace_bytes = 0;
+    p->tile = nullptr;
+    rc = FC_OK;
+  } else if (d.ndim == 1) rc = plan_1d(p);
   else rc = plan_nd(p);
   if (rc != FC_OK) { delete p; return rc; }
   *out_plan = p;
@@ -795,7 +804,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 }
 
 long long fc_debug_grid(const fc_plan* plan) {
-  if (!plan) return 0;
+  if (!plan || plan->d.dtype != FC_F32) return 0;
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
     const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
@@ -809,6 +818,10 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   (void)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
   const fc_plan& p = *plan;
+  if (p.d.dtype == FC_F64) {
+    FC_HIP(hipMemcpyAsync(w_hat, weight, p.spectrum_bytes, hipMemcpyDeviceToDevice, st));
+    return FC_OK;
+  }
   if (p.nd == 1) {
     fc::Spec1dArgs a;
     a.w = weight;
@@ -890,6 +903,21 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   hipStream_t st = (hipStream_t)hip_stream;
   const fc_plan& p = *plan;
   if (p.d.has_bias && !bias) return fail(FC_ERR_INVALID, "plan was created with has_bias=1 but bias is NULL");
+  if (p.d.dtype == FC_F64) {
+    if (stamps) return fail(FC_ERR_UNSUPPORTED, "no timestamp hook in the float64 kernel");
+    fc::DirectF64Args a{};
+    a.x = (const double*)x; a.w = (const double*)w_hat; a.bias = p.d.has_bias ? (const double*)bias : nullptr; a.y = (double*)y;
+    a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = (int)p.d.groups;
+    a.pad_mode = p.d.padding_mode; a.transposed = p.d.transposed;
+    for (int i = 0; i < 3; ++i) {          // axes right-aligned: leading axes of extent 1 for 1-D / 2-D
+      const int ax = i - (3 - p.nd);
+      const bool live = ax >= 0;
+      a.S[i] = live ? (int)p.d.spatial[ax] : 1; a.K[i] = live ? (int)p.d.kernel[ax] : 1; a.O[i] = live ? (int)p.out_sp[ax] : 1;
+      a.stride[i] = live ? (int)p.d.stride[ax] : 1; a.pad[i] = live ? (int)p.d.padding[ax] : 0; a.dil[i] = live ? (int)p.d.dilation[ax] : 1;
+    }
+    FC_HIP(fc::launch_direct_f64(a, st));
+    return FC_OK;
+  }
   if (p.nd == 1) {
     fc::Conv1dArgs a;
     a.x = x; a.wspec = (const fc::f4*)w_hat; a.bias = p.d.has_bias ? bias : nullptr; a.y = y;

@@ -41,6 +41,7 @@ struct TileImpl {
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();
 FC_DECLARE_TILE(8, 1)
+FC_DECLARE_TILE(8, 2)
 FC_DECLARE_TILE(16, 1)
 FC_DECLARE_TILE(16, 2)
 FC_DECLARE_TILE(32, 1)

@@ -20,15 +20,19 @@ from .utils import to_ntuple
 __all__ = ["fft_conv", "fft_conv_transpose", "complex_matmul", "to_ntuple", "transform_kernel", "KernelSpectrum"]
 
 
-def _require_gpu_f32(name: str, t: Tensor):
+_DTYPE_CODES = {torch.float32: 0, torch.float64: 1}      # enum fc_dtype
+
+
+def _require_gpu_f32(name: str, t: Tensor, dtype: torch.dtype = torch.float32):
+    """Device + dtype gate of everything handed to the library (``dtype``: the signal's, float32 or float64)."""
     if not t.is_cuda:
         raise RuntimeError(
             f"fft_conv_pytorch_amd: `{name}` is on {t.device}; this implementation runs on ROCm devices only "
             f"(no CPU fallback). Move the tensor to 'cuda'.")
-    if t.dtype != torch.float32:
-        raise TypeError(f"fft_conv_pytorch_amd: `{name}` has dtype {t.dtype}; the kernels compute in float32 "
-                        f"(float16 / bfloat16 tensors are accepted when signal, kernel and bias share the dtype; "
-                        f"float64 is not supported)")
+    if t.dtype != dtype or dtype not in _DTYPE_CODES:
+        raise TypeError(f"fft_conv_pytorch_amd: `{name}` has dtype {t.dtype}; signal, kernel and bias must share one of "
+                        f"float32 (the FFT kernels), float64 (direct float64 kernel) or float16 / bfloat16 (computed in "
+                        f"float32)")
 
 
 class KernelSpectrum:
@@ -103,16 +107,17 @@ def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, g
                 f"(need kernel.shape[1] * groups == in_channels and out_channels % groups == 0)")
     if bias is not None and tuple(bias.shape) != (cout,):
         raise ValueError(f"bias must have shape ({cout},), got {tuple(bias.shape)}")
+    dtype = signal.dtype if signal.dtype in _DTYPE_CODES else torch.float32
     key = (n, int(signal.shape[0]), cin, cout, groups,
            tuple(int(s) for s in signal.shape[2:]), tuple(int(k) for k in kernel.shape[2:]),
            tuple(int(s) for s in stride_), tuple(int(p) for p in padding_), tuple(int(d) for d in dilation_),
            _native.PAD_MODES[padding_mode], bias is not None, int(tile_hint), bool(transposed),
-           tuple(int(o) for o in output_padding_))
+           tuple(int(o) for o in output_padding_), _DTYPE_CODES[dtype])
     # host-side validation is complete; only now touch the device library
-    _require_gpu_f32("signal", signal)
-    _require_gpu_f32("kernel", kernel)
+    _require_gpu_f32("signal", signal, dtype)
+    _require_gpu_f32("kernel", kernel, dtype)
     if bias is not None:
-        _require_gpu_f32("bias", bias)
+        _require_gpu_f32("bias", bias, dtype)
     dev = _same_device(signal=signal, kernel=kernel, bias=bias)
     index = _device_index(dev)
     plan = _native.lookup_plan(index, key)
@@ -126,7 +131,7 @@ def _plan_for(signal: Tensor, kernel: Tensor, bias, stride, padding, dilation, g
 
 def transform_kernel(plan, kernel: Tensor) -> KernelSpectrum:
     """Kernel transform (dilate, zero-pad, FFT, conjugate) on the device; rows a2 + a6."""
-    _require_gpu_f32("kernel", kernel)
+    _require_gpu_f32("kernel", kernel, plan.dtype)
     kernel = kernel.detach().contiguous()
     if _device_index(kernel.device) != plan.device_index:
         raise ValueError(f"kernel is on {kernel.device} but the plan was made for cuda:{plan.device_index}")
@@ -140,7 +145,7 @@ def transform_kernel(plan, kernel: Tensor) -> KernelSpectrum:
 
 def _launch_forward(signal: Tensor, spectrum: KernelSpectrum, bias_c: Optional[Tensor]) -> Tensor:
     plan = spectrum.plan
-    out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=torch.float32, device=signal.device)
+    out = torch.empty((signal.shape[0], plan.key[3]) + plan.out_spatial, dtype=plan.dtype, device=signal.device)
     ws = new_workspace(plan, signal.device)
     stream = torch.cuda.current_stream(signal.device).cuda_stream
     plan.forward(signal.data_ptr(), spectrum.buf.data_ptr(), bias_c.data_ptr() if bias_c is not None else None,
@@ -152,6 +157,8 @@ def _forward_native(signal: Tensor, spectrum: KernelSpectrum, bias: Optional[Ten
     signal = signal.detach().contiguous()
     bias_c = bias.detach().contiguous() if bias is not None else None
     index = _device_index(signal.device)
+    if signal.dtype != spectrum.plan.dtype:
+        raise TypeError(f"signal is {signal.dtype} but the plan was made for {spectrum.plan.dtype}")
     if spectrum.plan.device_index != index or spectrum.buf.device != signal.device:
         raise ValueError(f"signal is on {signal.device} but the kernel spectrum / plan belong to "
                          f"cuda:{spectrum.plan.device_index}")

@@ -30,7 +30,12 @@ enum fc_status {
 };
 
 enum fc_pad_mode { FC_PAD_CONSTANT = 0, FC_PAD_REFLECT = 1, FC_PAD_REPLICATE = 2, FC_PAD_CIRCULAR = 3 };
-enum fc_dtype { FC_F32 = 0 };
+enum fc_dtype {
+  FC_F32 = 0,  /* the FFT kernels; every float* below is float */
+  FC_F64 = 1   /* float64 tensors: x, weight, w_hat, bias and y are double (pass them through the float* / void*
+                  parameters); a direct time-domain kernel computes the same function in float64 (the reference is
+                  dtype-agnostic); fc_wgrad1d and the profiling hook are float32-only */
+};
 
 /* Problem descriptor: the arguments of functional.py:19-28 after to_ntuple
  * (utils.py:4-20) has been applied on the host side.  Axis order is the tensor

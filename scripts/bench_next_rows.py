@@ -112,3 +112,64 @@ def ref_step(i):
 
 report("forward + backward, this library (autograd.Function)", timed(ours_step, args.iters), n_out, bwd_bytes)
 report("forward + backward, reference algorithm via torch.fft autograd, same GPU", timed(ref_step, args.iters), n_out, bwd_bytes)
+
+# transposed convolution forward + backward (differentiable since round 2): dX is a forward plan, dW the weight gradient
+# with the roles of signal and gradient swapped
+gr = [g.clone().requires_grad_(True) for g in gs[:3]]
+
+
+def ours_t_step(i):
+    g = gr[i % 3]
+    g.grad = None
+    tconv.zero_grad(set_to_none=True)
+    tconv(g).sum().backward()
+
+
+wtr = tconv.weight.detach().clone().requires_grad_(True)
+btr = tconv.bias.detach().clone().requires_grad_(True)
+
+
+def torch_t_step(i):
+    g = gr[i % 3]
+    g.grad = None
+    wtr.grad = None
+    btr.grad = None
+    F.conv_transpose1d(g, wtr, btr).sum().backward()
+
+
+t_bwd_bytes = t_bytes + 4 * (B * C * L + B * C * Lout + C * C * K + C) + 4 * (B * C * Lout + B * C * L)
+report("transposed forward + backward, this library", timed(ours_t_step, args.iters), B * C * L, t_bwd_bytes)
+report("transposed forward + backward, torch conv_transpose1d autograd (MIOpen), same GPU",
+       timed(torch_t_step, max(3, args.iters // 10)), B * C * L, t_bwd_bytes)
+
+# 2-D forward + backward (weight gradient through forward plans with batch and channels swapped)
+B2, S2, K2 = 4, 256, 15
+conv2 = fca.FFTConv2d(C, C, K2, bias=True).to(dev)
+x2 = [torch.randn(B2, C, S2, S2, device=dev, requires_grad=True) for _ in range(3)]
+o2 = S2 - K2 + 1
+n2 = B2 * C * o2 * o2
+b2_bytes = 4 * (B2 * C * S2 * S2 + C * C * K2 * K2 + C + n2) * 2 + 4 * (B2 * C * S2 * S2 + n2 + C * C * K2 * K2 + C)
+
+
+def ours_2d_step(i):
+    x = x2[i % 3]
+    x.grad = None
+    conv2.zero_grad(set_to_none=True)
+    conv2(x).sum().backward()
+
+
+w2r = conv2.weight.detach().clone().requires_grad_(True)
+b2r = conv2.bias.detach().clone().requires_grad_(True)
+
+
+def torch_2d_step(i):
+    x = x2[i % 3]
+    x.grad = None
+    w2r.grad = None
+    b2r.grad = None
+    F.conv2d(x, w2r, b2r).sum().backward()
+
+
+report(f"2-D forward + backward B{B2} {C}->{C} {S2}x{S2} k{K2}, this library", timed(ours_2d_step, args.iters), n2, b2_bytes)
+report(f"2-D forward + backward B{B2} {C}->{C} {S2}x{S2} k{K2}, torch conv2d autograd (MIOpen), same GPU",
+       timed(torch_2d_step, max(3, args.iters // 10)), n2, b2_bytes)

@@ -115,7 +115,7 @@ def test_channel_blocking_1d(cin, cout, groups):
     assert orc.rel_err(_hip(x, w, b, **kw), y_ref) < REL_TOL
 
 
-@pytest.mark.parametrize("tile", [64, 256, 512, 1024, 2048, 4096])
+@pytest.mark.parametrize("tile", [64, 128, 256, 512, 1024, 2048, 4096])
 @pytest.mark.parametrize("stride,dilation", [(1, 1), (3, 2)])
 def test_every_tile_geometry_1d(tile, stride, dilation, monkeypatch):
     """Force each FFT tile length (all (P, S) register/lane-split geometries) on a multi-tile row."""

@@ -329,7 +329,7 @@ def test_nd_rows_longer_than_4096():
     assert got.shape == want.shape and _rel(got, want) < REL_TOL
 
 
-@pytest.mark.parametrize("xtile", [64, 256])
+@pytest.mark.parametrize("xtile", [64, 128, 256])
 def test_nd_forced_x_tiles_match_single_transform(xtile, monkeypatch):
     """The same problems with and without x tiles (FFTCONV_XTILE forces tiles on rows that would fit one FFT):
     2-D / 3-D, strides, padding modes, backward through the tiled plans."""
@@ -405,5 +405,72 @@ def test_string_padding_and_half_precision_inputs():
         assert yh.dtype == dt
         want = F.conv1d(xh.double(), wh.double(), bh.double(), padding=32)
         assert _rel(yh, want) < tol
-    with pytest.raises(TypeError, match="float64 is not supported"):
-        fft_conv(torch.zeros(1, 2, 16, device=DEV, dtype=torch.float64), torch.zeros(2, 2, 3, device=DEV, dtype=torch.float64))
+    with pytest.raises(TypeError, match="must share"):
+        fft_conv(torch.zeros(1, 2, 16, device=DEV, dtype=torch.float64), torch.zeros(2, 2, 3, device=DEV))
+
+
+def test_float64_tensors_direct_kernel():
+    """float64 in, float64 out (the reference is dtype-agnostic: functional.py:19-89 runs in float64 on the CPU): the
+    FC_F64 plans' direct kernel against torch's float64 convolutions at 1e-10 -- forward with every padding mode,
+    stride, dilation, groups in 1-D / 2-D / 3-D, transposed with output_padding, gradients, modules."""
+    import fft_conv_pytorch_amd as fca
+    from fft_conv_pytorch_amd.functional import fft_conv, fft_conv_transpose
+    gen = torch.Generator().manual_seed(64)
+    tol = 1e-10
+    cases = [
+        ((2, 4, 200), (6, 2, 7), dict(groups=2, stride=3, padding=5, dilation=2, padding_mode="reflect")),
+        ((2, 3, 20, 33), (5, 3, 3, 5), dict(stride=(1, 2), padding=(2, 1), dilation=(2, 1), padding_mode="circular")),
+        ((1, 4, 9, 12, 10), (2, 2, 2, 3, 4), dict(groups=2, stride=(1, 2, 1), padding=(1, 0, 2), dilation=(2, 1, 1), padding_mode="constant")),
+        ((2, 2, 64), (3, 2, 6), dict(padding=3, padding_mode="replicate")),
+        ((2, 8, 3000), (8, 8, 129), dict(padding=64)),
+    ]
+    for xs, ws, kw in cases:
+        nd = len(xs) - 2
+        x = torch.randn(*xs, generator=gen, dtype=torch.float64).to(DEV).requires_grad_()
+        w = torch.randn(*ws, generator=gen, dtype=torch.float64).to(DEV).requires_grad_()
+        b = torch.randn(ws[0], generator=gen, dtype=torch.float64).to(DEV).requires_grad_()
+        mode = kw.get("padding_mode", "constant")
+        pad = kw.get("padding", 0)
+        pads = (pad,) * nd if isinstance(pad, int) else tuple(pad)
+        kwt = {k: v for k, v in kw.items() if k not in ("padding", "padding_mode")}
+        xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+        if mode == "constant":
+            want = getattr(F, f"conv{nd}d")(xr, wr, br, padding=pads, **kwt)
+        else:
+            flat = []
+            for p_ in reversed(pads):
+                flat += [p_, p_]
+            want = getattr(F, f"conv{nd}d")(F.pad(xr, flat, mode=mode), wr, br, **kwt)
+        got = fft_conv(x, w, b, **kw)
+        assert got.dtype == torch.float64 and got.shape == want.shape
+        assert _rel(got, want) < tol, (xs, kw, _rel(got, want))
+        gy = torch.randn(want.shape, generator=gen, dtype=torch.float64).to(DEV)
+        got.backward(gy)
+        want.backward(gy)
+        for name, a_, b_ in (("dX", x.grad, xr.grad), ("dW", w.grad, wr.grad), ("db", b.grad, br.grad)):
+            assert _rel(a_, b_) < tol, (name, xs, kw, _rel(a_, b_))
+    # transposed, with output_padding >= stride on one axis
+    x = torch.randn(2, 4, 9, 11, generator=gen, dtype=torch.float64).to(DEV).requires_grad_()
+    w = torch.randn(4, 3, 3, 4, generator=gen, dtype=torch.float64).to(DEV).requires_grad_()
+    kw = dict(stride=(2, 3), padding=(1, 2), output_padding=(2, 1), dilation=(3, 1), groups=2)
+    xr, wr = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    want = F.conv_transpose2d(xr, wr, None, **kw)
+    got = fft_conv_transpose(x, w, None, **kw)
+    assert got.shape == want.shape and _rel(got, want) < tol
+    gy = torch.randn(want.shape, generator=gen, dtype=torch.float64).to(DEV)
+    got.backward(gy)
+    want.backward(gy)
+    assert _rel(x.grad, xr.grad) < tol and _rel(w.grad, wr.grad) < tol
+    # modules follow .double()
+    layer = fca.FFTConv1d(3, 5, 9, padding=4).to(DEV).double().eval()
+    xin = torch.randn(2, 3, 100, device=DEV, dtype=torch.float64)
+    with torch.no_grad():
+        assert _rel(layer(xin), F.conv1d(xin, layer.weight, layer.bias, padding=4)) < tol
+    # G5 fixtures (float32 reference outputs) are reproduced to float32 accuracy by the float64 kernel too
+    for n, kind, meta, xg, wg, bg, gyg, gold in gu.g5_cases():
+        if xg.size > 5000:
+            continue
+        fn = fft_conv if kind == "fwd" else fft_conv_transpose
+        y = fn(torch.from_numpy(xg).double().to(DEV), torch.from_numpy(wg).double().to(DEV),
+               bias=torch.from_numpy(bg).double().to(DEV), **gu.g5_kwargs(kind, meta))
+        gu.check_entry(y.cpu().numpy(), gold["y"], 2e-6)

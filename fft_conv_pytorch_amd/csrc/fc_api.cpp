@@ -149,6 +149,7 @@ struct fc_plan {
   int Fx;                     // Tx/2 + 1
   int nxt, Vx, Fxt;           // overlap-save tiles along the rows axis (nxt = 1: one full-length transform), valid
                               // stride-1 samples per tile, bin columns per plane = nxt * Fx
+  int nyt, Vy;                // the same for the middle axis of a 3-D problem (one c2c launch per tile)
   int nd_cob, nd_Cog_pad;
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
@@ -533,9 +534,22 @@ static int plan_nd(fc_plan* p) {
   p->Fx = p->tx->T / 2 + 1;
   p->Fxt = p->nxt * p->Fx;
   p->tm = nullptr;
+  p->nyt = 1;
+  p->Vy = nd == 3 ? p->Lf[1] : 0;
   if (nd == 3) {
     p->tm = smallest_tile_at_least(p->Sp[1]);
-    if (!p->tm) return fail(FC_ERR_UNSUPPORTED, "padded extent %d of the middle axis exceeds the largest FFT (4096)", p->Sp[1]);
+    const char* env = getenv("FFTCONV_YTILE");       // testing knob: force middle-axis tiles of this length
+    const int64_t kdy = p->kd[1];
+    int forced = env ? atoi(env) : 0;
+    if (forced && (!find_tile(forced) || find_tile(forced)->T < kdy)) forced = 0;
+    if (!p->tm || forced) {
+      const fc::TileImpl* t = forced ? find_tile(forced) : find_tile(kdy <= 1025 ? 2048 : 4096);
+      if (!t || t->T < kdy)
+        return fail(FC_ERR_UNSUPPORTED, "dilated kernel extent %lld along the middle axis exceeds the largest FFT (4096)", (long long)kdy);
+      p->tm = t;
+      p->Vy = (int)(t->T - kdy + 1);
+      p->nyt = (int)((p->Lf[1] + p->Vy - 1) / p->Vy);
+    }
   }
   // channel blocking of the fused (complex) pass: one sequence per channel
   p->nd_cob = std::min(p->CB, p->Cog);
@@ -581,11 +595,11 @@ static int plan_nd(fc_plan* p) {
     a_w = Co * p->Cig * Fx * (size_t)p->kd[0];            // S1w[(o,i)][fx][y<Kd]
     b_w = 0;
   } else {
-    const size_t Ty = (size_t)p->tm->T;
+    const size_t Ty = (size_t)p->tm->T, Tys = Ty * (size_t)p->nyt;  // kernel side / signal side (all middle-axis tiles)
     ncol = Fx * Ty;
     a_sig = std::max(B * Ci * p->Sp[0] * Fs * p->Sp[1],            // S1[(b,ci)][zp][xt,fx][yp]
-                     B * Co * Fs * Ty * (size_t)p->out_sp[0]);      // O2[(b,co)][xt,fx][fy][z_out]
-    b_sig = std::max(B * Ci * Fs * Ty * p->Sp[0],                   // S2[(b,ci)][xt,fx][fy][zp]
+                     B * Co * Fs * Tys * (size_t)p->out_sp[0]);     // O2[(b,co)][xt,fx][yt,fy][z_out]
+    b_sig = std::max(B * Ci * Fs * Tys * p->Sp[0],                  // S2[(b,ci)][xt,fx][yt,fy][zp]
                      B * Co * (size_t)p->out_sp[0] * Fs * (size_t)p->out_sp[1]);   // O1[(b,co)][z_out][xt,fx][y_out]
     a_w = Co * p->Cig * (size_t)p->kd[0] * Fx * (size_t)p->kd[1];
     b_w = Co * p->Cig * Fx * Ty * (size_t)p->kd[0];
@@ -806,7 +820,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->d.dtype != FC_F32) return 0;
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
-    const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T;
+    const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T * plan->nyt;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
   }
   if (plan->pers_nb) return (long long)plan->pers_items * 16;   // one record per wave (up to 16) of every work item
@@ -867,7 +881,7 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   const float norm = 1.0f / ((float)p.tx->T * (float)p.tile->T * (nd == 3 ? (float)p.tm->T : 1.0f));
   fc::C2CArgs c{};
   c.Cig = p.Cig; c.Cog = p.Cog; c.Cig_pad = p.Cig_pad; c.Cog_pad = p.nd_Cog_pad; c.scale = norm;
-  c.NV = 0; c.stride = 1;
+  c.NV = 0; c.stride = 1; c.noff = 0;
   if (nd == 2) {
     // S1w[(o,i)][fx][y<Kd] -> wspec[..][fx][fy]
     c.src = wsA; c.dst = (fc::f2*)w_hat; c.twA = p.tw.twA; c.twB = p.tw.twB;
@@ -995,7 +1009,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   fc::RowsC2RArgs o{};
   o.dst = y; o.bias = p.d.has_bias ? bias : nullptr; o.twA = p.twx.twA; o.twB = p.twx.twB;
   o.NA = B * Co; o.Fx = p.Fx; o.Cout = Co; o.nxt = p.nxt; o.Vx = p.Vx;
-  f.wfx = p.Fx; f.wty = nd == 3 ? p.tm->T : 1; f.wncol = f.wfx * f.wty;
+  f.wfx = p.Fx; f.wty = nd == 3 ? p.tm->T : 1; f.wrep = nd == 3 ? p.nyt : 1; f.wncol = f.wfx * f.wty;
   o.NV = p.Lf[nd - 1]; o.stride = p.ostride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
   o.NY = (int)p.out_sp[nd - 2]; o.NYa = o.NY;
 
@@ -1008,20 +1022,30 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     const int Ty = p.tm->T, Szp = p.Sp[0], Syp = p.Sp[1], Lzo = (int)p.out_sp[0], Lyo = (int)p.out_sp[1];
     fc::C2CArgs c{};
     c.scale = 1.f; c.store_mode = 0; c.twA = p.twm.twA; c.twB = p.twm.twB;
-    // S1[(b,ci)][zp][fx][yp] -> S2[(b,ci)][fx][fy][zp]
-    c.src = wsA; c.dst = wsB; c.NA = B * Ci; c.NC = Fs; c.NB = Szp; c.NLEN = Syp;
+    // S1[(b,ci)][zp][fx][yp] -> S2[(b,ci)][fx][yt,fy][zp]   (one launch per middle-axis tile yt)
+    const int nyt = p.nyt, Vy = p.Vy;
+    const long long Tys = (long long)nyt * Ty;
+    c.NA = B * Ci; c.NC = Fs; c.NB = Szp;
     c.sa = (long long)Szp * Fs * Syp; c.sb = (long long)Fs * Syp; c.sc = Syp;
-    c.ta = (long long)Fs * Ty * Szp; c.tc = (long long)Ty * Szp; c.tf = Szp;
-    c.NV = 0; c.stride = 1;
-    FC_HIP(p.tm->c2c_fwd(c, st));
-    f.src = wsB; f.dst = wsA; f.ncol = Fs * Ty;
+    c.ta = (long long)Fs * Tys * Szp; c.tc = Tys * Szp; c.tf = Szp;
+    c.NV = 0; c.stride = 1; c.noff = 0;
+    for (int yt = 0; yt < nyt; ++yt) {
+      c.src = wsA + (size_t)yt * Vy; c.dst = wsB + (size_t)yt * Ty * Szp;
+      c.NLEN = std::min(Ty, Syp - yt * Vy);
+      FC_HIP(p.tm->c2c_fwd(c, st));
+    }
+    f.src = wsB; f.dst = wsA; f.ncol = (int)(Fs * Tys);
     FC_HIP(p.tile->fusedc(p.CB, f, st));
-    // O2[(b,co)][fx][fy][z_out] -> O1[(b,co)][z_out][fx][y_out]
-    c.src = wsA; c.dst = wsB; c.NA = B * Co; c.NC = Fs; c.NB = Lzo;
-    c.sa = (long long)Fs * Ty * Lzo; c.sc = (long long)Ty * Lzo; c.sb = Lzo;
+    // O2[(b,co)][fx][yt,fy][z_out] -> O1[(b,co)][z_out][fx][y_out]
+    c.NA = B * Co; c.NC = Fs; c.NB = Lzo;
+    c.sa = (long long)Fs * Tys * Lzo; c.sc = Tys * Lzo; c.sb = Lzo;
     c.ta = (long long)Lzo * Fs * Lyo; c.tb = (long long)Fs * Lyo; c.tc = Lyo;
-    c.NV = p.Lf[1]; c.stride = p.ostride[1];
-    FC_HIP(p.tm->c2c_inv(c, st));
+    c.stride = p.ostride[1];
+    for (int yt = 0; yt < nyt; ++yt) {
+      c.src = wsA + (size_t)yt * Ty * Lzo; c.dst = wsB;
+      c.noff = yt * Vy; c.NV = std::min(Vy, p.Lf[1] - yt * Vy);
+      FC_HIP(p.tm->c2c_inv(c, st));
+    }
     o.src = wsB; o.NC = Lzo;
     FC_HIP(p.tx->rows_c2r(o, st));
   }

@@ -234,8 +234,9 @@ struct C2CArgs {
   // weights mode: a = o*Cig + i (o over all Cout)
   int Cig, Cog, Cig_pad, Cog_pad;
   float scale;
-  // inverse mode: valid samples and decimation
-  int NV, stride;
+  // inverse mode: valid samples and decimation; noff = position of this launch's sample 0 on the axis (overlap-save
+  // tiles along the middle axis run one launch per tile)
+  int NV, stride, noff;
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -325,8 +326,9 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       const int n = nbase + P * k;
-      const int idx = n / a.stride;
-      if (n < a.NV && idx * a.stride == n) out[idx] = v[k];
+      const int ng = a.noff + n;
+      const int idx = ng / a.stride;
+      if (n < a.NV && idx * a.stride == ng) out[idx] = v[k];
     }
   }
 }
@@ -452,9 +454,9 @@ struct FusedCArgs {
   const f2* twB;
   int B, Cin, Cout, G, Cig, Cog, Cig_pad, Cog_pad, cob, n_ochunks;
   int ncol, NLEN;        // columns per image, valid input length (zero beyond)
-  int wfx, wty, wncol;   // kernel-spectrum column of signal column col: ((col / wty) % wfx) * wty + col % wty -- with x
-                         // tiles the signal has nxt * wfx bin columns that share the wfx columns of the kernel;
-                         // wncol = wfx * wty spectrum columns per (o, ip)
+  int wfx, wty, wrep, wncol;   // kernel-spectrum column of signal column col = ((xt*wfx + fx)*wrep + yt)*wty + fy:
+                         // ((col / (wty*wrep)) % wfx) * wty + col % wty -- the x tiles (xt) and middle-axis tiles (yt) of
+                         // the signal share the wfx * wty columns of the kernel; wncol = wfx * wty columns per (o, ip)
   int Kd, V, ntiles, Lfull, NVo, stride;
   int accumulate;
   unsigned long long* stamps;   // profiling hook: 8 timestamps per workgroup, else null
@@ -506,7 +508,7 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   const int n_ichunks = a.Cig_pad / CIB;
   const int t0 = tile * a.V;
   const size_t wcol = (size_t)a.wncol * T;                         // f4 per (o, ip)
-  const int wc = ((col / a.wty) % a.wfx) * a.wty + col % a.wty;
+  const int wc = ((col / (a.wty * a.wrep)) % a.wfx) * a.wty + col % a.wty;
   const f4* wgrp = a.wspec + (size_t)g * a.Cog_pad * (a.Cig_pad / 2) * wcol + (size_t)wc * T;
 
   for (int ic = 0; ic < n_ichunks; ++ic) {

@@ -301,6 +301,8 @@ def test_nd_rows_longer_than_4096():
         ((1, 4, 6, 10, 5000), (4, 2, 3, 3, 17), dict(groups=2, padding=(1, 1, 8), dilation=(1, 2, 3))),
         ((2, 2, 40, 4500), (2, 2, 3, 1200), dict(padding=(1, 100), padding_mode="circular")),     # 4096-point x tiles
         ((1, 3, 33, 6000), (5, 3, 4, 9), dict(stride=(1, 3), padding=(0, 4), padding_mode="replicate")),
+        ((1, 2, 4, 4300, 12), (2, 2, 2, 9, 3), dict(stride=(1, 2, 1), padding=(0, 4, 1), padding_mode="replicate")),   # long MIDDLE axis
+        ((1, 2, 3, 4200, 4200), (2, 1, 2, 5, 7), dict(groups=2)),                                  # middle and last axis tiled
     ]
     for xs, ws, kw in cases:
         x = torch.randn(*xs, generator=gen, dtype=torch.float64)
@@ -331,8 +333,9 @@ def test_nd_rows_longer_than_4096():
 
 @pytest.mark.parametrize("xtile", [64, 128, 256])
 def test_nd_forced_x_tiles_match_single_transform(xtile, monkeypatch):
-    """The same problems with and without x tiles (FFTCONV_XTILE forces tiles on rows that would fit one FFT):
-    2-D / 3-D, strides, padding modes, backward through the tiled plans."""
+    """The same problems with and without x tiles (FFTCONV_XTILE forces tiles on rows that would fit one FFT;
+    FFTCONV_YTILE the same for the middle axis of 3-D plans): 2-D / 3-D, strides, padding modes, backward through the
+    tiled plans."""
     from fft_conv_pytorch_amd import _native
     from fft_conv_pytorch_amd.functional import fft_conv
     gen = torch.Generator().manual_seed(78 + xtile)
@@ -340,23 +343,28 @@ def test_nd_forced_x_tiles_match_single_transform(xtile, monkeypatch):
         ((2, 4, 30, 300), (6, 2, 5, 7), dict(groups=2, padding=(2, 3), stride=(1, 2))),
         ((2, 3, 25, 500), (3, 3, 3, 31), dict(padding=(1, 15), padding_mode="reflect")),
         ((1, 2, 7, 9, 400), (4, 2, 3, 2, 11), dict(dilation=(1, 1, 2), padding=(1, 0, 10), padding_mode="circular")),
+        ((2, 2, 6, 300, 70), (2, 2, 2, 9, 5), dict(stride=(1, 2, 1), padding=(1, 4, 2), padding_mode="reflect")),
     ]
     for xs, ws, kw in cases:
         x = torch.randn(*xs, generator=gen).to(DEV).requires_grad_()
         w = torch.randn(*ws, generator=gen).to(DEV).requires_grad_()
         b = torch.randn(ws[0], generator=gen).to(DEV)
-        monkeypatch.delenv("FFTCONV_XTILE", raising=False)
+        for var in ("FFTCONV_XTILE", "FFTCONV_YTILE"):
+            monkeypatch.delenv(var, raising=False)
         _native.clear_plan_cache()
         y0 = fft_conv(x, w, b, **kw)
         gy = torch.randn(y0.shape, generator=gen).to(DEV)
         gx0, gw0 = torch.autograd.grad(y0, (x, w), gy)
-        monkeypatch.setenv("FFTCONV_XTILE", str(xtile))
-        _native.clear_plan_cache()
-        y1 = fft_conv(x, w, b, **kw)
-        gx1, gw1 = torch.autograd.grad(y1, (x, w), gy)
-        monkeypatch.delenv("FFTCONV_XTILE", raising=False)
-        _native.clear_plan_cache()
-        assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 1e-5 and _rel(gw1, gw0) < 1e-5, (xs, kw)
+        for forced in (("FFTCONV_XTILE",), ("FFTCONV_YTILE",), ("FFTCONV_XTILE", "FFTCONV_YTILE")):
+            for var in forced:
+                monkeypatch.setenv(var, str(xtile))
+            _native.clear_plan_cache()
+            y1 = fft_conv(x, w, b, **kw)
+            gx1, gw1 = torch.autograd.grad(y1, (x, w), gy)
+            for var in forced:
+                monkeypatch.delenv(var, raising=False)
+            _native.clear_plan_cache()
+            assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 1e-5 and _rel(gw1, gw0) < 1e-5, (xs, kw, forced)
 
 
 # ----------------------------------------------------------------------------- N4 supersets: padding strings, half precision

@@ -5,7 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <vector>
-#include "../../fft_conv_pytorch_amd/csrc/planes3d.hpp"
+#include "../experiments/planes3d.hpp"
 
 using namespace fc;
 

@@ -943,6 +943,11 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)stamps;
+    {
+      static const int stagger = getenv("FFTCONV_STAGGER") ? atoi(getenv("FFTCONV_STAGGER")) : 0;   // tuning knob
+      static const int stagger_from = getenv("FFTCONV_STAGGER_FROM") ? atoi(getenv("FFTCONV_STAGGER_FROM")) : 256;
+      a.exp_stagger = stagger; a.exp_stagger_from = stagger_from;
+    }
     a.segmented = p.nseg > 1; a.pos_shift = 0;
     if (p.pers_nb) {
       for (int j = 0; j < p.nseg; ++j) {

@@ -111,6 +111,14 @@ __host__ __device__ constexpr int bitrev(int v, int bits) {
   return r;
 }
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 // one radix-2 DIT butterfly with twiddle w = exp(DIR*2*pi*i*q/64); q is a
 // compile-time constant after unrolling, so the branches fold away.
 template <int DIR>
@@ -131,21 +139,27 @@ __device__ __forceinline__ void bfly(f2& a, f2& b, int q) {
   }
 }
 
-// P-point FFT on registers, natural order in, natural order out.
-template <int P, int DIR>
-__device__ __forceinline__ void fft_regs(f2 (&v)[P]) {
+// P-point FFT on registers, natural order in, natural order out.  `hook(stage)` runs after every radix-2 stage
+// (stage = 0 .. log2(P)-1 as an integral_constant): the batch-sharing kernel issues a few of the next work item's
+// global loads there, so their issue cost spreads over the butterflies instead of blocking the wave in one burst.
+struct NoHook {
+  template <class T> __device__ __forceinline__ void operator()(T) const {}
+};
+template <int P, int DIR, class H = NoHook>
+__device__ __forceinline__ void fft_regs(f2 (&v)[P], H&& hook = H{}) {
   constexpr int LG = ilog2(P);
   f2 t[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) t[bitrev(i, LG)] = v[i];
-#pragma unroll
-  for (int len = 2; len <= P; len <<= 1) {
+  static_for<0, LG>([&](auto sc) {
+    constexpr int len = 2 << decltype(sc)::value;
 #pragma unroll
     for (int blk = 0; blk < P; blk += len) {
 #pragma unroll
       for (int j = 0; j < len / 2; ++j) bfly<DIR>(t[blk + j], t[blk + j + len / 2], j * (64 / len));
     }
-  }
+    hook(sc);
+  });
 #pragma unroll
   for (int i = 0; i < P; ++i) v[i] = t[i];
 }
@@ -188,13 +202,6 @@ __device__ __forceinline__ f2 dpp_xor2(f2 v) { return mk2(dpp_xor2(v.x), dpp_xor
 //   lds_read_strided(v, base)   requests v[i] = base[i * STRIDE]           (nothing waits)
 //   lds_arrive(v)               s_waitcnt lgkmcnt(0), then hands the values to the compiler
 // LDS returns in order, so compiler-issued LDS traffic mixed in between stays correct.
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 __device__ __forceinline__ unsigned lds_off(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
@@ -277,10 +284,10 @@ __device__ __forceinline__ void passA_fft_twiddle_store(f2 (&v)[G::P], f2* __res
   passA_twiddle_apply<G, DIR>(v, w, lseq, n2);
 }
 // same with the twiddle table in LDS
-template <class G, int DIR>
+template <class G, int DIR, class H = NoHook>
 __device__ __forceinline__ void passA_fft_twiddle_store_lds(f2 (&v)[G::P], f2* __restrict__ lseq, int n2,
-                                                            const f2* __restrict__ twl) {
-  fft_regs<G::P, DIR>(v);
+                                                            const f2* __restrict__ twl, H&& hook = H{}) {
+  fft_regs<G::P, DIR>(v, hook);
   f2 w[G::P];
   lds_read_strided<G::P, G::N2, 1>(w, twl + n2);
   lds_arrive<G::P, 1>(w);
@@ -336,19 +343,19 @@ __device__ __forceinline__ void nat_load(f2 (&v)[G::P], const f2* __restrict__ l
 // k of this lane is X[k1 + P*(k + P*j)]   (k1 = tseq >> log2(S)).
 //   twB[r*P + k] = exp(-2*pi*i*r*k/N2) (forward sign): used by the S = 4 split, whose per-lane
 //   twiddles differ between the three non-trivial lanes of a quad (S = 2 uses compile-time roots)
-template <class G, int DIR>
-__device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq, BufRsrc twB) {
+template <class G, int DIR, class H = NoHook>
+__device__ __forceinline__ int passB_compute(f2 (&v)[G::P], int tseq, BufRsrc twB, H&& hook = H{}) {
   if constexpr (G::S == 4) {
     const int r4 = tseq & 3;
     f2 w[G::P];
 #pragma unroll
     for (int k = 1; k < G::P; ++k) w[k] = buf_load_f32x2(twB, (unsigned)(r4 * G::P * 8), k * 8);
     __builtin_amdgcn_sched_barrier(0);
-    fft_regs<G::P, DIR>(v);
+    fft_regs<G::P, DIR>(v, hook);
 #pragma unroll
     for (int k = 1; k < G::P; ++k) v[k] = (DIR > 0) ? cmulc(v[k], w[k]) : cmul(v[k], w[k]);
   } else {
-    fft_regs<G::P, DIR>(v);
+    fft_regs<G::P, DIR>(v, hook);
   }
   if constexpr (G::S == 1) {
     return 0;

@@ -36,7 +36,12 @@ torch.cuda.synchronize()
 y = layer(x)
 torch.cuda.synchronize()
 plan.debug_set_stamps(None)
-raw = buf.cpu().numpy().reshape(-1, 16, 16).astype(np.float64) * 0.01   # [item][wave][stamp], 100 MHz ticks -> us
+ticks = buf.cpu().numpy().reshape(-1, 16, 16).astype(np.float64)
+raw = ticks * 0.01   # [item][wave][stamp], 100 MHz ticks -> us
+if (ticks[:, 0, 13] > 0).any():     # slots 12 / 13: shader clock counter at the item's start / end
+    ghz = (ticks[:, 0, 13] - ticks[:, 0, 12]) / np.maximum(ticks[:, 0, 11] - ticks[:, 0, 0], 1) * 0.1
+    print(f"shader clock held over an item (s_memtime / s_memrealtime): median {np.median(ghz):.3f} GHz, "
+          f"p10 {np.percentile(ghz, 10):.3f}, p90 {np.percentile(ghz, 90):.3f}")
 grid = raw.shape[0]
 nw = int((raw[:, :, 0] > 0).sum(axis=1).max())
 st = raw[:, 0, :]
@@ -59,8 +64,9 @@ life = st[:, 11] - st[:, 0]
 print(f"work item lifetime median {np.median(life):.2f} us; start times: p50 {np.median(st[:, 0] - t0):.2f} "
       f"p90 {np.percentile(st[:, 0] - t0, 90):.2f} max {(st[:, 0] - t0).max():.2f} us")
 half = st[:, 0] - t0 > 0.5 * np.median(life)
-for name, sel in (("first round", ~half), ("later rounds", half)):
+for name, sel in (("first round", ~half), ("later rounds", half), ("first round, slowest 10 %", ~half & (life > np.percentile(life[~half], 90)))):
     if sel.any():
+        print(f"-- {name}: median dt per phase: " + "  ".join(f"{names[i]} {np.median(st[sel, i] - st[sel, i - 1]):.2f}" for i in range(1, 12)))
         print(f"{name}: n={int(sel.sum())} lifetime p10/p50/p90/max = "
               f"{np.percentile(life[sel], 10):.1f}/{np.median(life[sel]):.1f}/{np.percentile(life[sel], 90):.1f}/{life[sel].max():.1f} us, "
               f"end p50/max = {np.median(st[sel, 11] - t0):.1f}/{(st[sel, 11] - t0).max():.1f} us")

@@ -1,0 +1,324 @@
+// dense1d.hpp -- 1-D FFT convolution for MANY channels per group: spectra through HBM, contraction on the matrix pipe.
+//
+// The fused kernels (conv1d_pers / conv1d_wide) keep a tile's spectra in LDS and contract them on the VALU; with
+// more than 8 input AND output channels per group every out-chunk workgroup of conv1d_wide repeats the forward
+// transforms of all input chunks, and the per-bin contraction (functional.py:11-16, `complex_matmul`: an einsum over
+// the input channels) is a dense [tiles x Cin] x [Cin x Cout] complex product per frequency bin -- the one place
+// of the path where MFMA has a second large dimension to work on.  Three launches per slab of M = batch x tiles rows:
+//
+//   dense_fwd   tile -> packed-pair FFT -> unpacked spectra   X[g][f][m][i]   (f = 0 .. T/2, complex, 2 X really)
+//   dense_gemm  per (g, f):  Y[m][o] = sum_i X[m][i] * H[i][o]  as the real product  [Xr Xi] x [[Hr Hi], [-Hi Hr]]
+//               on v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate: same arithmetic type as the VALU kernels)
+//   dense_inv   Y[g][f][m][o] -> packed pairs -> inverse FFT -> valid window + bias (functional.py:76-87)
+//
+// H is the kernel spectrum of spectrum1d.hpp (conjugated, scaled by 1/(2T)) re-laid bin-major by dense_spec.
+// Rows of X / Y are channel-contiguous (Kc / Nc complex values), so the transposing stores and loads of the two FFT
+// kernels move 256-byte runs (16 channel pairs x 16 bytes) and the GEMM reads its A panel in whole rows.
+#pragma once
+#include "nd_passes.hpp"
+
+namespace fc {
+
+struct DenseArgs {
+  const float* x;        // (B, Cin, L)
+  float* y;              // (B, Cout, Lout)
+  const float* bias;     // (Cout) or null
+  f2* X;                 // [G][NF][mcount][Kc]
+  f2* Y;                 // [G][NF][mcount][Nc]
+  const f2* Hd;          // [G][NF][Kc][Nc]
+  const f2* twA;
+  const f2* twB;
+  int B, Cin, Cout, G, Cig, Cog;
+  int Kc, Nc;            // channels per group padded to a multiple of 8
+  int L, pad, pad_mode, V, ntiles, Lfull, Lout;
+  int m0, mcount;        // this slab: rows m0 .. m0 + mcount - 1 of M = B * ntiles (row m = batch m / ntiles, tile m % ntiles)
+};
+
+// ------------------------------------------------------------------------------------------ dense_fwd
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void dense_fwd_kernel(const DenseArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T, NF = T / 2 + 1;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  static_assert(NT == NSEQ * G::TS, "one thread slot per point group of every sequence");
+  static_assert(NT % NSEQ == 0 && (NSEQ & (NSEQ - 1)) == 0, "bins are dealt out to groups of NSEQ lanes");
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int ncb = (a.Kc / 2 + NSEQ - 1) / NSEQ;          // channel blocks of NSEQ pairs
+  int id = blockIdx.x;
+  const int ml = id % a.mcount; id /= a.mcount;
+  const int cb = id % ncb;
+  const int g = id / ncb;
+  const int m = a.m0 + ml, b = m / a.ntiles, tile = m % a.ntiles;
+  const int ci0 = 2 * (cb * NSEQ + sq);                   // this sequence's channel pair inside the group
+  const bool act = ci0 < a.Kc;
+  const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;  // channels past Cig are padding: zero spectra
+
+  f2 v[P];
+  {
+    const PadMap pm = make_padmap(a.pad_mode, a.L);
+    const float* xbase = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L;
+    const BufRsrc xg = make_rsrc(xbase, (unsigned)((size_t)a.Cig * a.L * 4));
+    const int pos0 = tile * a.V - a.pad;
+    const bool interior = (pos0 >= 0) && (pos0 + T <= a.L);
+    const unsigned ro0 = (unsigned)ci0 * (unsigned)a.L * 4u, ro1 = ro0 + (unsigned)a.L * 4u;
+    if (interior && has1) {
+      const unsigned v0 = ro0 + (unsigned)(pos0 + tseq) * 4u, v1 = ro1 + (unsigned)(pos0 + tseq) * 4u;
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
+        v[n1].y = buf_load_f32(xg, v1, G::N2 * n1 * 4);
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int pos = pos0 + G::N2 * n1 + tseq;
+        v[n1].x = buf_load_f32(xg, padded_offset(ro0, pos, a.L, a.pad, pm, has0), 0);
+        v[n1].y = buf_load_f32(xg, padded_offset(ro1, pos, a.L, a.pad, pm, has1), 0);
+      }
+    }
+  }
+  fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
+  __syncthreads();
+  // unpack (2 X_even, 2 X_odd of every pair) and store channel-contiguous: NSEQ neighbouring lanes write the
+  // NSEQ pairs of one bin = 16 * NSEQ bytes in one run
+  const int s = tid % NSEQ, fsub = tid / NSEQ;
+  constexpr int NFS = NT / NSEQ;
+  const bool st_ok = 2 * (cb * NSEQ + s) < a.Kc;
+  const f2* z = lds + s * LSEQP;
+  f4* out = reinterpret_cast<f4*>(a.X + (((size_t)g * NF) * a.mcount + ml) * a.Kc + 2 * (cb * NSEQ + s));
+  const size_t fstride = (size_t)a.mcount * a.Kc / 2;      // f4 units between bins
+  for (int f = fsub; f < NF; f += NFS) {
+    const f2 zf = z[G::nat(f)], zg = z[G::nat((T - f) & (T - 1))];
+    const f2 xe = add_conj(zf, zg), xo = sub_conj_divi(zf, zg);
+    f4 o; o.x = xe.x; o.y = xe.y; o.z = xo.x; o.w = xo.y;
+    if (st_ok) out[(size_t)f * fstride] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dense_inv
+template <int P, int S, int NSEQ, int NT>
+__global__ __launch_bounds__(NT) void dense_inv_kernel(const DenseArgs a) {
+  using G = Geo<P, S>;
+  constexpr int T = G::T, NF = T / 2 + 1;
+  constexpr int LSEQP = SeqLayout<G>::LSEQP;
+  static_assert(NT == NSEQ * G::TS, "one thread slot per point group of every sequence");
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
+  const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
+  const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
+  const int ncb = (a.Nc / 2 + NSEQ - 1) / NSEQ;
+  int id = blockIdx.x;
+  const int ml = id % a.mcount; id /= a.mcount;
+  const int cb = id % ncb;
+  const int g = id / ncb;
+  const int m = a.m0 + ml, b = m / a.ntiles, tile = m % a.ntiles;
+  const int co0 = 2 * (cb * NSEQ + sq);
+  const bool act = co0 < a.Nc;
+  const int cg0 = g * a.Cog + co0;
+  const bool ok0 = co0 < a.Cog, ok1 = co0 + 1 < a.Cog;
+  const float bias0 = (a.bias && ok0) ? a.bias[cg0] : 0.f;
+  const float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
+  {
+    // gather: lane (s, bin) reads the two channels of pair s at one bin (16 bytes; NSEQ lanes = one run) and
+    // re-packs them as Z[f] = Ye + i Yo, Z[T-f] = conj(Ye) + i conj(Yo)
+    const int s = tid % NSEQ, fsub = tid / NSEQ;
+    constexpr int NFS = NT / NSEQ;
+    const bool ld_ok = 2 * (cb * NSEQ + s) < a.Nc;
+    f2* z = lds + s * LSEQP;
+    const f4* in = reinterpret_cast<const f4*>(a.Y + (((size_t)g * NF) * a.mcount + ml) * a.Nc + 2 * (cb * NSEQ + s));
+    const size_t fstride = (size_t)a.mcount * a.Nc / 2;
+    if (ld_ok) {
+      for (int f = fsub; f < NF; f += NFS) {
+        const f4 yv = in[(size_t)f * fstride];
+        const f2 ya = mk2(yv.x, yv.y), yb = mk2(yv.z, yv.w);
+        z[G::nat(f)] = add_pi(ya, yb);
+        if (f != 0 && f != T / 2) z[G::nat(T - f)] = conj_add_iconj(ya, yb);
+      }
+    }
+  }
+  __syncthreads();
+  f2 v[P];
+  const int j = inv_to_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
+  if (act) {
+    const int o1 = tseq >> G::LGS;
+    const int t0 = tile * a.V;
+    const int limit = min(a.V, a.Lfull - t0);
+    const int nbase = o1 + P * P * j;
+    float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase);
+    float* y1 = y0 + a.Lout;
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+      if (nbase + P * k < limit) {
+        if (ok0) y0[P * k] = v[k].x + bias0;
+        if (ok1) y1[P * k] = v[k].y + bias1;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dense_gemm
+// One workgroup = (group g, bin f, block of 128 rows m, block of 8*NCT output channels).  Wave w owns the 16 real
+// output columns of column tile w % NCT (= 8 complex output channels) and the row tiles w / NCT, w / NCT + 8 / NCT, ...
+// The B operand (this bin's [[Hr Hi], [-Hi Hr]] columns) lives in registers for the whole workgroup, the A panel
+// (128 rows x 2*KCH floats, rows as stored by dense_fwd) is staged once per K chunk in LDS and read by all waves.
+// MFMA operand layout (checked by scripts/ubench/ubench_mfma16.hip): A[i][k] in lane 16 k + i, B[k][j] in lane
+// 16 k + j, D[4 (lane / 16) + r][lane % 16] in register r.
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kDenseMB = 128;        // rows per workgroup
+
+// K2N = pairs of MFMA k steps per K chunk: a chunk holds KCH = 4 K2N complex input channels (16, 32 or 64; the
+// launcher picks the smallest that covers Kc, or 64 and several chunks).  The k loops are unconditional -- a
+// guarded MFMA makes hipcc copy the accumulator around every single instruction -- so the last chunk's missing
+// channels are zero columns of the LDS panel and zero B values.
+template <int NCT, int K2N>
+__global__ __launch_bounds__(512, 4) void dense_gemm_kernel(const DenseArgs a, int nf) {   // (4 waves per SIMD = two workgroups per CU: one loads while the other multiplies)
+  constexpr int NW = 8, MS = NW / NCT;          // waves; row-tile subsets
+  constexpr int MTW = (kDenseMB / 16) / MS;     // row tiles per wave
+  constexpr int KCH = 4 * K2N;                  // complex input channels per K chunk
+  constexpr int RS = 2 * KCH + 4;               // LDS row pitch in floats: conflict-free 8-byte reads of (row i, k pair)
+  static_assert(NCT == 2 || NCT == 4 || NCT == 8, "column tiles per workgroup");
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  float* pa = reinterpret_cast<float*>(lds);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = w % NCT, ms = w / NCT;
+  const int nmb = (a.mcount + kDenseMB - 1) / kDenseMB;
+  const int nnb = (a.Nc + 8 * NCT - 1) / (8 * NCT);
+  int id = blockIdx.x;
+  const int mb = id % nmb; id /= nmb;
+  const int nb = id % nnb; id /= nnb;
+  const int f = id % nf;
+  const int g = id / nf;
+  const int row0 = mb * kDenseMB;
+  const int i16 = lane & 15, kq = lane >> 4;
+  // this lane's output column: real column nr of the block -> complex channel o, component comp
+  const int nr = ct * 16 + i16;
+  const int o = nb * 8 * NCT + (nr >> 1), comp = nr & 1;
+  const bool col_ok = o < a.Nc;
+  // buffer resources over this (group, bin)'s rows of X and matrix of H: anything out of range reads as zero, so
+  // neither the panel loads nor the B loads need a branch (and all of them are in flight together)
+  const BufRsrc xr = make_rsrc(a.X + (((size_t)g * nf + f) * a.mcount) * a.Kc, (unsigned)((size_t)a.mcount * a.Kc * 8));
+  const BufRsrc hr = make_rsrc(a.Hd + (((size_t)g * nf + f) * a.Kc) * a.Nc, (unsigned)((size_t)a.Kc * a.Nc * 8));
+
+  v4f acc[MTW];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc0 = 0; kc0 < a.Kc; kc0 += KCH) {
+    const int kch = min(KCH, a.Kc - kc0);                  // complex channels of this chunk (a multiple of 8)
+    // ---- A panel -> LDS (whole rows of the chunk, 16 bytes per lane; rows past the slab and channels past the
+    // chunk are zero)
+    {
+      constexpr int Q4 = KCH / 2;                          // float4 per panel row
+      constexpr int NIT = kDenseMB * Q4 / 512;
+      const int q4 = kch / 2;
+      f4 val[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
+        const unsigned off = (c4 < q4) ? (unsigned)((((row0 + r) * a.Kc) + kc0 + 2 * c4) * 8) : 0xFFFFFFFFu;
+        val[it] = buf_load_f32x4(xr, off, 0);
+      }
+      __syncthreads();                                     // (previous chunk's reads are done)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
+        *reinterpret_cast<f4*>(pa + r * RS + 4 * c4) = val[it];
+      }
+    }
+    // (B loads come after the panel has left the registers: with both sets live the kernel needs more than the 128
+    // VGPRs that let two workgroups share a CU)
+    // ---- B fragments: step kk covers the real rows k = 8 (kk / 2) + 2 kq + (kk % 2) of the chunk
+    float bfrag[2 * K2N];
+#pragma unroll
+    for (int kk = 0; kk < 2 * K2N; ++kk) {
+      const int k = 8 * (kk >> 1) + 2 * kq + (kk & 1);
+      const int i = kc0 + (k >> 1), part = k & 1;          // complex input channel; 0: times Xr, 1: times Xi
+      const unsigned off = (col_ok && (k >> 1) < kch) ? (unsigned)(((i * a.Nc + o) * 2 + (comp ^ part)) * 4) : 0xFFFFFFFFu;
+      const float hv = buf_load_f32(hr, off, 0);
+      bfrag[kk] = (part == 1 && comp == 0) ? -hv : hv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MTW; ++t) {
+      const int mt = ms + MS * t;
+      if (row0 + mt * 16 < a.mcount) {                     // (wave-uniform: whole row tiles past the slab are skipped)
+        const float* prow = pa + (mt * 16 + i16) * RS + 2 * kq;
+        v4f c = acc[t];
+#pragma unroll
+        for (int k2 = 0; k2 < K2N; ++k2) {
+#if defined(FC_DENSE_DBG) && FC_DENSE_DBG == 1      // diagnostic build: no LDS reads in the k loop
+          const f2 av = mk2(bfrag[0], bfrag[1]);
+#else
+          const f2 av = *reinterpret_cast<const f2*>(prow + 8 * k2);
+#endif
+#if defined(FC_DENSE_DBG) && FC_DENSE_DBG == 2      // diagnostic build: no MFMA
+          c[k2 & 3] += av.x * bfrag[2 * k2] + av.y * bfrag[2 * k2 + 1];
+#else
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bfrag[2 * k2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bfrag[2 * k2 + 1], c, 0, 0, 0);
+#endif
+        }
+        acc[t] = c;
+      }
+    }
+  }
+  // ---- store: register r of row tile mt is row 16 mt + 4 (lane / 16) + r, this lane's column.  The tiles go through
+  // the (now free) panel area so that whole rows of the block leave in 16-byte pieces: written straight from the
+  // accumulators they are 4-byte stores in 64-byte runs, and the kernel spent two thirds of its time on them.
+  constexpr int NCOL = 16 * NCT;                 // real columns of the block
+  constexpr int OS = NCOL + 4;                   // LDS row pitch of the output block (floats)
+  __syncthreads();                               // every wave is done reading the panel
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) {
+    const int mt = ms + MS * t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pa[(mt * 16 + 4 * kq + r) * OS + nr] = acc[t][r];
+  }
+  __syncthreads();
+  {
+    constexpr int Q4 = NCOL / 4;                 // float4 per output row of the block
+    float* yf = reinterpret_cast<float*>(a.Y + (((size_t)g * nf + f) * a.mcount) * a.Nc) + (size_t)nb * NCOL;
+    const int ncol_ok = min(NCOL, 2 * a.Nc - nb * NCOL);      // real columns that exist (a multiple of 16)
+    for (int idx = tid; idx < kDenseMB * Q4; idx += 512) {
+      const int r = idx / Q4, c4 = idx % Q4;
+      if (row0 + r < a.mcount && 4 * c4 < ncol_ok)
+        *reinterpret_cast<f4*>(yf + (size_t)(row0 + r) * (2 * a.Nc) + 4 * c4) = *reinterpret_cast<const f4*>(pa + r * OS + 4 * c4);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dense_spec
+// Kernel spectrum of spectrum1d.hpp ([g][o][input pair][T/2] float4, bins 0 and T/2 packed into slot 0) -> bin-major
+// complex matrices Hd[g][f][i][o], f = 0 .. T/2.
+struct DenseSpecArgs {
+  const f4* wspec;
+  f2* Hd;
+  int G, Kc, Nc, T;
+};
+template <int UNUSED>   // (a template only so that every translation unit may carry the definition)
+__global__ __launch_bounds__(256) void dense_spec_kernel(const DenseSpecArgs a) {
+  const int NF = a.T / 2 + 1;
+  const size_t total = (size_t)a.G * NF * a.Kc * a.Nc;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+    const int o = (int)(idx % a.Nc);
+    size_t r = idx / a.Nc;
+    const int i = (int)(r % a.Kc); r /= a.Kc;
+    const int f = (int)(r % NF);
+    const int g = (int)(r / NF);
+    const f4* row = a.wspec + (((size_t)g * a.Nc + o) * (a.Kc / 2) + (i >> 1)) * (a.T / 2);
+    f2 h;
+    if (f == 0 || f == a.T / 2) {
+      const f4 h0 = row[0];
+      const float re = (f == 0) ? ((i & 1) ? h0.z : h0.x) : ((i & 1) ? h0.w : h0.y);
+      h = mk2(re, 0.f);
+    } else {
+      const f4 hv = row[f];
+      h = (i & 1) ? mk2(hv.z, hv.w) : mk2(hv.x, hv.y);
+    }
+    a.Hd[idx] = h;
+  }
+}
+
+}  // namespace fc

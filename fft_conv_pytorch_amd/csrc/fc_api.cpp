@@ -158,6 +158,9 @@ struct fc_plan {
   int pers_grid, pers_items;
   int chunk_launches;         // general kernel launched once per input chunk, later chunks add into y (see plan_1d)
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
+  int dense;                  // >= 16 channels per group on both sides: spectra through HBM + MFMA contraction (dense1d.hpp)
+  int dense_mslab;            // rows (batch x tiles) per slab of that pipeline's workspace
+  size_t dense_pers_bytes;    // its kernel spectrum before the bin-major re-layout (scratch of fc_transform_kernel)
   int nseg, seg_taps;         // 1-D: the kernel runs in nseg segments of seg_taps taps (1 = whole kernel)
   int64_t kd_plan;            // dilated extent the tiles are planned for (of one segment)
   size_t seg_spectrum_bytes;  // kernel-spectrum bytes of one segment
@@ -261,7 +264,29 @@ static int plan_1d_inner(fc_plan* p) {
   p->pers_nb_choice = 0;
   p->ph = 1;
   p->wide = 0;
+  p->dense = 0;
   {
+    // 16 or more channels per group on BOTH sides, stride 1, kernel within the 1024 tile: transforms and contraction
+    // in separate launches, the contraction as one real GEMM per frequency bin on the matrix pipe (dense1d.hpp).
+    // FFTCONV_DENSE=0 keeps the fused kernels (A/B runs).
+    const char* env = getenv("FFTCONV_DENSE");
+    const int want_dense = env ? atoi(env) : 1;
+    const fc::TileImpl* dt = find_tile(1024);
+    // Measured against the fused kernels (scripts/dense_check.py, us): 128->96 M = 30 rows 76 / 175; 32->32 M = 144
+    // 57 / 82; 64->64 M = 152 124 / 152; but 24->40 M = 18 44 / 33, 16->24 x 2 groups M = 26 41 / 27, 16->16 M = 2
+    // 31 / 23: three launches need work to amortise -- at least 32 channels a side and 64 K row-channel products.
+    // FFTCONV_DENSE=2 forces the pipeline for every shape it can run (tests).
+    const int64_t Kd_d = p->kd[0];
+    const int64_t Md = d.batch * ((p->Lf[0] + (1025 - Kd_d) - 1) / std::max<int64_t>(1, 1025 - Kd_d));
+    const bool pays = want_dense == 2 || (p->Cig >= 32 && p->Cog >= 32 && Md * p->Cig * p->Cog >= 65536);
+    if (want_dense && pays && dt && dt->dense && p->nseg == 1 && p->CB == 8 && p->Cig >= 16 && p->Cog >= 16 && d.stride[0] == 1 &&
+        p->up[0] == 1 && !p->diag && !p->bd_gs && Kd <= 769 && (!forced_tile || forced_tile == 1024) &&
+        (int64_t)p->Cig * d.spatial[0] * 4 < ((int64_t)1 << 32)) {
+      p->dense = 1;
+      forced_tile = 1024;
+    }
+  }
+  if (!p->dense) {
     // more than 8 input channels per group, whole out-chunks, stride 1: the register-accumulating
     // batch-sharing kernel (1024 or 2048 tile, whichever keeps at least a quarter of the tile valid).
     // Short kernels stay with the general kernel and its small tiles (measured: 16->16, k = 33, L = 4096:
@@ -277,7 +302,7 @@ static int plan_1d_inner(fc_plan* p) {
       }
     }
   }
-  if (p->wide) {
+  if (p->wide || p->dense) {
     // tile fixed above
   } else if (!forced_tile) {
     int rc = choose_fast_path(p, &forced_tile);
@@ -293,7 +318,7 @@ static int plan_1d_inner(fc_plan* p) {
   if (attempt == 1) {
     // No tile holds the kernel together with the second (running-sum) LDS region of a multi-chunk plan:
     // launch the general kernel once per input chunk instead, chunks after the first adding into y.
-    if (!p->accumulate || p->wide || forced_tile) break;
+    if (!p->accumulate || p->wide || p->dense || forced_tile) break;
     p->accumulate = 0;
     p->chunk_launches = 1;
   }
@@ -301,7 +326,7 @@ static int plan_1d_inner(fc_plan* p) {
     const fc::TileImpl* t = tiles[i];
     if (forced_tile && t->T != forced_tile) continue;
     if (t->T < Kd_t) continue;
-    const size_t lds = p->wide ? t->wide_lds : (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2);
+    const size_t lds = p->wide ? t->wide_lds : (p->dense ? 0 : (size_t)(p->accumulate ? 2 : 1) * NPI * t->lseq * sizeof(fc::f2));
     if (lds > lds_cap) continue;
     if (t->NT / (t->P * t->S) < NPI) continue;
     const int64_t V = t->T - Kd_t + 1;
@@ -335,6 +360,23 @@ static int plan_1d_inner(fc_plan* p) {
   p->workspace_bytes = 0;
   int rc = get_twiddles(best, &p->tw);
   if (rc != FC_OK) return rc;
+  if (p->dense) {
+    // spectrum: bin-major complex matrices; workspace: one slab of X and Y rows (<= 192 MiB), or the fused-layout
+    // spectrum while the kernel is being transformed
+    const size_t NF = (size_t)best->T / 2 + 1;
+    p->dense_pers_bytes = p->spectrum_bytes;
+    p->spectrum_bytes = (size_t)p->G * NF * p->Cig_pad * p->Cog_pad * sizeof(fc::f2);
+    p->seg_spectrum_bytes = p->spectrum_bytes;
+    const int64_t M = d.batch * (int64_t)p->ntiles;
+    const size_t row_bytes = (size_t)p->G * NF * (size_t)(p->Cig_pad + p->Cog_pad) * sizeof(fc::f2);
+    int64_t slab = (int64_t)(((size_t)192 << 20) / row_bytes) / 128 * 128;
+    slab = std::max<int64_t>(128, slab);
+    if (const char* e = getenv("FFTCONV_DENSE_SLAB")) slab = std::max(1, atoi(e));     // testing knob: rows per slab
+    p->dense_mslab = (int)std::min<int64_t>(M, slab);
+    p->workspace_bytes = std::max(row_bytes * (size_t)p->dense_mslab, p->dense_pers_bytes);
+    p->pers_nb = 0; p->d_items = nullptr; p->pers_items = 0; p->pers_grid = 0;
+    return FC_OK;
+  }
   rc = plan_1d_persistent(p);
   if (rc == FC_OK && p->ph > 1 && p->pers_nb == 0)
     return fail(FC_ERR_INVALID, "internal: phase plan without the batch-sharing kernel");
@@ -809,7 +851,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
   const fc_plan& p = *plan;
   layout[0] = p.tile ? p.tile->T : 0;
   layout[1] = p.ph; layout[2] = p.nseg; layout[3] = p.seg_taps;
-  layout[4] = p.diag; layout[5] = p.bd_gs; layout[6] = p.wide; layout[7] = p.pers_nb;
+  layout[4] = p.diag; layout[5] = p.bd_gs; layout[6] = p.dense ? 2 : p.wide; layout[7] = p.pers_nb;
   if (p.nd != 1) {   // N-d: the spectrum is laid out over the row / middle-axis transform lengths too
     layout[1] = p.tx ? p.tx->T : 0; layout[2] = p.tm ? p.tm->T : 0; layout[3] = p.nd_cob;   // (x tiles share one kernel spectrum)
     layout[4] = layout[5] = layout[6] = layout[7] = 0;
@@ -853,6 +895,16 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.Krow = (int)p.d.kernel[0];
     const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
     const int grid = (a.nseq + per_wg - 1) / per_wg;
+    if (p.dense) {
+      // transform into the scratch area in the fused kernels' layout, then re-lay bin-major for the GEMM
+      if (!workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
+      a.k0 = 0; a.K = (int)p.d.kernel[0]; a.wspec = (fc::f4*)workspace;
+      FC_HIP(p.tile->spec1d(a, grid, p.lds_spec, st));
+      fc::DenseSpecArgs ds;
+      ds.wspec = (const fc::f4*)workspace; ds.Hd = (fc::f2*)w_hat; ds.G = p.G; ds.Kc = p.Cig_pad; ds.Nc = p.Cog_pad; ds.T = p.tile->T;
+      FC_HIP(p.tile->dense_spec(ds, st));
+      return FC_OK;
+    }
     for (int j = 0; j < p.nseg; ++j) {
       a.k0 = j * p.seg_taps;
       a.K = std::min(p.seg_taps, (int)p.d.kernel[0] - a.k0);
@@ -930,6 +982,27 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
       a.stride[i] = live ? (int)p.d.stride[ax] : 1; a.pad[i] = live ? (int)p.d.padding[ax] : 0; a.dil[i] = live ? (int)p.d.dilation[ax] : 1;
     }
     FC_HIP(fc::launch_direct_f64(a, st));
+    return FC_OK;
+  }
+  if (p.nd == 1 && p.dense) {
+    if (!workspace) return fail(FC_ERR_INVALID, "workspace is NULL but %zu bytes are required", p.workspace_bytes);
+    fc::DenseArgs a{};
+    const size_t NF = (size_t)p.tile->T / 2 + 1;
+    a.x = x; a.y = y; a.bias = p.d.has_bias ? bias : nullptr; a.Hd = (const fc::f2*)w_hat;
+    a.twA = p.tw.twA; a.twB = p.tw.twB;
+    a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = p.G;
+    a.Cig = p.Cig; a.Cog = p.Cog; a.Kc = p.Cig_pad; a.Nc = p.Cog_pad;
+    a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode;
+    a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
+    const int64_t M = p.d.batch * (int64_t)p.ntiles;
+    for (int64_t m0 = 0; m0 < M; m0 += p.dense_mslab) {
+      a.m0 = (int)m0; a.mcount = (int)std::min<int64_t>(p.dense_mslab, M - m0);
+      a.X = (fc::f2*)workspace;
+      a.Y = a.X + (size_t)p.G * NF * (size_t)a.mcount * (size_t)a.Kc;
+      FC_HIP(p.tile->dense(0, a, st));
+      FC_HIP(p.tile->dense(1, a, st));
+      FC_HIP(p.tile->dense(2, a, st));
+    }
     return FC_OK;
   }
   if (p.nd == 1) {

@@ -5,6 +5,7 @@
 #include "conv1d_pers.hpp"
 #include "conv1d_wide.hpp"
 #include "nd_passes.hpp"
+#include "dense1d.hpp"
 #include "spectrum1d.hpp"
 #include "wgrad1d.hpp"
 
@@ -37,6 +38,10 @@ struct TileImpl {
   hipError_t (*wgrad1d)(const WGradArgs& a, int grid, hipStream_t st);
   hipError_t (*wgrad1d_diag)(const WGradArgs& a, int grid, hipStream_t st);   // depthwise blocks of 8 channels
   int wgrad_nb;          // items per iteration of that kernel
+  // many-channel 1-D pipeline (dense1d.hpp), built for the 1024-point tile only (else null): which = 0 forward
+  // transforms, 1 per-bin GEMM (MFMA), 2 inverse transforms
+  hipError_t (*dense)(int which, const DenseArgs& a, hipStream_t st);
+  hipError_t (*dense_spec)(const DenseSpecArgs& a, hipStream_t st);
 };
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();

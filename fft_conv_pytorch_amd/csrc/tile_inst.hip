@@ -3,6 +3,7 @@
 // geometries compile in parallel.
 #include "fc_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -258,6 +259,66 @@ hipError_t wgrad_diag_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
 constexpr int kWgradNb = 0;
 #endif
 
+#if FC_P == 32 && FC_S == 1
+// many-channel pipeline: channel pairs per workgroup in the two transform kernels
+#ifndef FC_DENSE_NSEQ
+#define FC_DENSE_NSEQ 8      // measured 64->64, B 8, L 16384, k 129: forward 21.1 / inverse 33.6 us at 8 (256 threads, two
+#endif                       // workgroups per CU), 24.0 / 35.3 us at 16 (512 threads, one per CU)
+constexpr int kDenseNseq = FC_DENSE_NSEQ;
+hipError_t dense_dispatch(int which, const DenseArgs& a, hipStream_t st) {
+  constexpr int NT = kDenseNseq * GG::TS;
+  const size_t lds_fft = (size_t)kDenseNseq * kLSEQP * sizeof(float2);
+  if (which == 0 || which == 2) {
+    const int nch = which == 0 ? a.Kc : a.Nc;
+    const long long ncb = (nch / 2 + kDenseNseq - 1) / kDenseNseq;
+    const long long grid = (long long)a.mcount * ncb * a.G;
+    if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+    static LdsOptIn done_f, done_i;
+    if (which == 0) {
+      auto k = dense_fwd_kernel<FC_P, FC_S, kDenseNseq, NT>;
+      hipError_t e = ensure_lds(k, lds_fft, &done_f);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds_fft, st, a);
+    } else {
+      auto k = dense_inv_kernel<FC_P, FC_S, kDenseNseq, NT>;
+      hipError_t e = ensure_lds(k, lds_fft, &done_i);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds_fft, st, a);
+    }
+    return hipGetLastError();
+  }
+  // GEMM: the widest column block that the output channels fill (8 channels per wave), the smallest K chunk that
+  // covers the input channels (or 64 and several chunks)
+  const int nf = kT / 2 + 1;
+  const int nct = a.Nc >= 64 ? 8 : (a.Nc >= 32 ? 4 : 2);
+  const int k2n = a.Kc <= 16 ? 4 : (a.Kc <= 32 ? 8 : 16);
+  const size_t lds = (size_t)kDenseMB * std::max(8 * k2n + 4, 16 * nct + 4) * sizeof(float);   // panel / output block
+  const long long nmb = (a.mcount + kDenseMB - 1) / kDenseMB, nnb = (a.Nc + 8 * nct - 1) / (8 * nct);
+  const long long grid = nmb * nnb * nf * a.G;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+#define FC_DENSE_GEMM(N, K)                                                      \
+  if (nct == N && k2n == K) {                                                    \
+    static LdsOptIn done;                                                        \
+    auto k = dense_gemm_kernel<N, K>;                                            \
+    hipError_t e = ensure_lds(k, lds, &done);                                    \
+    if (e != hipSuccess) return e;                                               \
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, st, a, nf);      \
+    return hipGetLastError();                                                    \
+  }
+  FC_DENSE_GEMM(8, 16) FC_DENSE_GEMM(8, 8) FC_DENSE_GEMM(8, 4)
+  FC_DENSE_GEMM(4, 16) FC_DENSE_GEMM(4, 8) FC_DENSE_GEMM(4, 4)
+  FC_DENSE_GEMM(2, 16) FC_DENSE_GEMM(2, 8) FC_DENSE_GEMM(2, 4)
+#undef FC_DENSE_GEMM
+  return hipErrorInvalidValue;
+}
+hipError_t dense_spec_dispatch(const DenseSpecArgs& a, hipStream_t st) {
+  const size_t total = (size_t)a.G * (a.T / 2 + 1) * a.Kc * a.Nc;
+  const unsigned grid = (unsigned)std::min<size_t>((total + 255) / 256, 65536);
+  hipLaunchKernelGGL(dense_spec_kernel<0>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+#endif
+
 }  // namespace
 
 #define FC_CAT_(a, b, c, d) a##b##c##d
@@ -275,7 +336,13 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
 #else
                                 nullptr, nullptr,
 #endif
-                                kWgradNb};
+                                kWgradNb,
+#if FC_P == 32 && FC_S == 1
+                                dense_dispatch, dense_spec_dispatch
+#else
+                                nullptr, nullptr
+#endif
+  };
   return &impl;
 }
 

@@ -350,6 +350,35 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
         for (int k = 0; k < P; ++k)
           if (nbase + P * k < limit) { y0[ystep * k] += v[k].x; y1[ystep * k] += v[k].y; }
+      } else if (!PHASES && S == 1) {
+        // Lane o1 holds samples o1 + P k.  For k < ka every lane is inside the valid window, k = ka is the one partly
+        // valid row of stores, later k are outside for every lane (ka is wave-uniform).  Buffer stores: one 32-bit
+        // offset register per output row, the step P k as the instruction's immediate.
+        const int ka = limit >= P ? (limit - P) / P + 1 : 0;
+        const BufRsrc yr = make_rsrc(a.y + ((size_t)b * a.Cout + (size_t)(g * a.Cog + oc * a.cob)) * a.Lout, (unsigned)((size_t)a.cob * a.Lout * 4));
+        const unsigned vo0 = (unsigned)((size_t)(2 * pr) * a.Lout + (size_t)(t0 + nbase)) * 4u, vo1 = vo0 + (unsigned)a.Lout * 4u;
+        // Blocks of 8 rows: a block below ka is straight-line code behind ONE scalar branch (per-row tests, even
+        // wave-uniform ones, cost more instructions than the stores they guard); only the block that holds row ka
+        // tests its rows, and there the lanes past the window get an offset outside the resource (store dropped).
+        static_for<0, P / 8>([&](auto bc) {
+          constexpr int k0 = 8 * decltype(bc)::value;
+          if (ka >= k0 + 8) {
+            static_for<k0, k0 + 8>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              buf_store_f32(v[k].x + bias0, yr, vo0, P * k * 4);
+              buf_store_f32(v[k].y + bias1, yr, vo1, P * k * 4);
+            });
+          } else if (ka >= k0) {
+            static_for<k0, k0 + 8>([&](auto kc) {
+              constexpr int k = decltype(kc)::value;
+              if (k <= ka) {
+                const unsigned dead = (nbase + P * k < limit) ? 0u : 0x80000000u;
+                buf_store_f32(v[k].x + bias0, yr, vo0 | dead, P * k * 4);
+                buf_store_f32(v[k].y + bias1, yr, vo1 | dead, P * k * 4);
+              }
+            });
+          }
+        });
       } else if (!PHASES) {
 #pragma unroll
         for (int k = 0; k < P; ++k)
@@ -374,15 +403,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   if (a.exp_stagger > 0 && (int)blockIdx.x >= a.exp_stagger_from) {
     for (int s = 0; s < a.exp_stagger; s += 16) __builtin_amdgcn_s_sleep(16);
   }
-  const bool noprefetch = a.exp_stagger == -1;   // diagnostic: the second item's samples are requested when it starts
   fetch(w0, va);                             // first item's samples and the twiddle table travel together
   for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
   __syncthreads();
-  run(w0, it0, va, two && !noprefetch, w1, vb);
-  if (two) {
-    if (noprefetch) fetch(w1, vb);
-    run(w1, it1, vb, false, w1, va);
-  }
+  run(w0, it0, va, two, w1, vb);
+  if (two) run(w1, it1, vb, false, w1, va);
 }
 
 }  // namespace fc

@@ -185,6 +185,10 @@ __device__ __forceinline__ f4 buf_load_f32x4(BufRsrc r, unsigned voff, unsigned 
   return o;
 }
 
+__device__ __forceinline__ void buf_store_f32(float v, BufRsrc r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+
 // ---- cross-lane helpers (DPP quad permutes: VALU rate, no LDS) --------------
 __device__ __forceinline__ float dpp_xor1(float v) {   // quad_perm [1,0,3,2]
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));

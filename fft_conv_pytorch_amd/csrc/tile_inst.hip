@@ -17,7 +17,10 @@ namespace {
 using GG = Geo<FC_P, FC_S>;
 constexpr int kT = GG::T;
 constexpr int kNSEQ_C = (8192 / kT) > 16 ? 16 : ((8192 / kT) < 2 ? 2 : (8192 / kT));
-constexpr int kNSEQ_R = kNSEQ_C / 2;
+#ifndef FC_ROWS_DIV
+#define FC_ROWS_DIV 2
+#endif
+constexpr int kNSEQ_R = (kNSEQ_C / FC_ROWS_DIV) < 1 ? 1 : (kNSEQ_C / FC_ROWS_DIV);
 constexpr int kLSEQP = SeqLayout<GG>::LSEQP;
 constexpr int kFusedMaxCib = (8 * kLSEQP * 8 <= 160 * 1024 && 8 * GG::TS <= 1024) ? 8 : 4;
 

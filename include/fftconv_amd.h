@@ -79,7 +79,8 @@ void fc_plan_destroy(fc_plan* plan);
  * (S-1)*stride - 2p + d(k-1) + output_padding + 1 (functional.py:144-154). */
 int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]);
 
-/* Bytes the caller must provide for the transformed kernel / the scratch area. */
+/* Bytes the caller must provide for the transformed kernel / the scratch area (N-d plans and the many-channel
+ * 1-D pipeline use a scratch area, in fc_transform_kernel AND fc_forward; 0 for the fused 1-D kernels). */
 size_t fc_kernel_spectrum_bytes(const fc_plan* plan);
 size_t fc_workspace_bytes(const fc_plan* plan);
 
@@ -88,7 +89,8 @@ int fc_plan_tile(const fc_plan* plan);
 
 /* Everything the byte layout of the kernel spectrum depends on besides the descriptor itself:
  * {tile, dilation phases, kernel segments, taps per segment, depthwise blocks, regrouped small groups,
- * wide-input kernel, batch items per workgroup}.  Two plans of equal descriptor (up to the batch size),
+ * wide-input kernel (2 = the many-channel pipeline: bin-major complex matrices for its per-bin GEMM), batch items
+ * per workgroup}.  Two plans of equal descriptor (up to the batch size),
  * equal fc_kernel_spectrum_bytes() and equal layout words accept each other's fc_transform_kernel()
  * output -- what a multi-GPU caller checks before broadcasting one rank's spectrum (the planner looks at
  * the local batch size).  No counterpart in the reference (it re-transforms the kernel on every call,

@@ -16,6 +16,8 @@ dev = torch.device("cuda", 0)
 SHAPES = [  # ndim, B, Cin, Cout, groups, size, k
     (1, 32, 8, 8, 1, 32768, 512),
     (1, 8, 64, 64, 1, 16384, 129),
+    (1, 5, 128, 96, 1, 4096, 257),
+    (1, 16, 32, 32, 1, 8192, 65),
     (1, 4, 32, 32, 1, 65536, 1025),
     (1, 16, 16, 16, 1, 4096, 33),
     (1, 64, 4, 4, 1, 8192, 2049),

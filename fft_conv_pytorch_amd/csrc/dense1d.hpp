@@ -32,6 +32,7 @@ struct DenseArgs {
   int Kc, Nc;            // channels per group padded to a multiple of 8
   int L, pad, pad_mode, V, ntiles, Lfull, Lout;
   int m0, mcount;        // this slab: rows m0 .. m0 + mcount - 1 of M = B * ntiles (row m = batch m / ntiles, tile m % ntiles)
+  int cus;               // CUs of the device (grid of the persistent GEMM)
 };
 
 // ------------------------------------------------------------------------------------------ dense_fwd
@@ -159,133 +160,159 @@ __global__ __launch_bounds__(NT) void dense_inv_kernel(const DenseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dense_gemm
-// One workgroup = (group g, bin f, block of 128 rows m, block of 8*NCT output channels).  Wave w owns the 16 real
-// output columns of column tile w % NCT (= 8 complex output channels) and the row tiles w / NCT, w / NCT + 8 / NCT, ...
-// The B operand (this bin's [[Hr Hi], [-Hi Hr]] columns) lives in registers for the whole workgroup, the A panel
-// (128 rows x 2*KCH floats, rows as stored by dense_fwd) is staged once per K chunk in LDS and read by all waves.
+// Persistent: one workgroup per CU walks units (group g, bin f, block of 8*NCT output channels, block of 128 rows m) and,
+// inside a unit, K chunks of KCH input channels.  Wave w owns the 16 real output columns of column tile w % NCT (= 8
+// complex output channels) and the row tiles w / NCT, w / NCT + 8 / NCT, ...  The B operand (this bin's
+// [[Hr Hi], [-Hi Hr]] columns) lives in registers, the A panel (128 rows x 2*KCH floats, rows as stored by dense_fwd) in
+// LDS, read by all waves.  The loads of step s+1 (panel into registers, B values) are issued BEFORE the MFMAs of step s
+// and land in the other LDS panel at the top of the next step: the one-shot form of this kernel (load, multiply, store
+// per workgroup; two workgroups per CU) moved its 114 MB at 1.9 TB/s and took 62 us where the MFMAs need 20.
 // MFMA operand layout (checked by scripts/ubench/ubench_mfma16.hip): A[i][k] in lane 16 k + i, B[k][j] in lane
 // 16 k + j, D[4 (lane / 16) + r][lane % 16] in register r.
 typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kDenseMB = 128;        // rows per workgroup
+// MB = rows per unit: 128, or 32 for slabs of few rows (M = batch x tiles <= 64: the units are then all spectrum
+// traffic and hardly any arithmetic; 35 KB of LDS and half the registers let two workgroups per CU keep twice the
+// loads in flight)
 
 // K2N = pairs of MFMA k steps per K chunk: a chunk holds KCH = 4 K2N complex input channels (16, 32 or 64; the
 // launcher picks the smallest that covers Kc, or 64 and several chunks).  The k loops are unconditional -- a
 // guarded MFMA makes hipcc copy the accumulator around every single instruction -- so the last chunk's missing
 // channels are zero columns of the LDS panel and zero B values.
-template <int NCT, int K2N>
-__global__ __launch_bounds__(512, 4) void dense_gemm_kernel(const DenseArgs a, int nf) {   // (4 waves per SIMD = two workgroups per CU: one loads while the other multiplies)
+template <int NCT, int K2N, int kDenseMB>
+__global__ __launch_bounds__(512, kDenseMB >= 128 ? 2 : 4) void dense_gemm_kernel(const DenseArgs a, int nf) {
   constexpr int NW = 8, MS = NW / NCT;          // waves; row-tile subsets
   constexpr int MTW = (kDenseMB / 16) / MS;     // row tiles per wave
   constexpr int KCH = 4 * K2N;                  // complex input channels per K chunk
   constexpr int RS = 2 * KCH + 4;               // LDS row pitch in floats: conflict-free 8-byte reads of (row i, k pair)
-  static_assert(NCT == 2 || NCT == 4 || NCT == 8, "column tiles per workgroup");
+  constexpr int NCOL = 16 * NCT;                // real columns of a unit
+  constexpr int OS = NCOL + 4;                  // LDS row pitch of the staged output block (floats)
+  constexpr int PANEL = kDenseMB * (RS > OS ? RS : OS);   // floats per LDS panel (also holds an output block)
+  constexpr int Q4 = KCH / 2;                   // float4 per panel row
+  constexpr int NIT = (kDenseMB * Q4 + 511) / 512;   // float4 per thread and panel (MB = 32 with small chunks: part of the threads)
+  static_assert((kDenseMB / 16) % MS == 0 && kDenseMB / 16 >= MS, "every wave owns whole row tiles");
+  static_assert(NCT == 2 || NCT == 4 || NCT == 8, "column tiles per unit");
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
-  float* pa = reinterpret_cast<float*>(lds);
+  float* pbase = reinterpret_cast<float*>(lds);
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct = w % NCT, ms = w / NCT;
   const int nmb = (a.mcount + kDenseMB - 1) / kDenseMB;
   const int nnb = (a.Nc + 8 * NCT - 1) / (8 * NCT);
-  int id = blockIdx.x;
-  const int mb = id % nmb; id /= nmb;
-  const int nb = id % nnb; id /= nnb;
-  const int f = id % nf;
-  const int g = id / nf;
-  const int row0 = mb * kDenseMB;
+  const int nkc = (a.Kc + KCH - 1) / KCH;
+  const long long U = (long long)a.G * nf * nnb * nmb;
   const int i16 = lane & 15, kq = lane >> 4;
-  // this lane's output column: real column nr of the block -> complex channel o, component comp
-  const int nr = ct * 16 + i16;
-  const int o = nb * 8 * NCT + (nr >> 1), comp = nr & 1;
-  const bool col_ok = o < a.Nc;
-  // buffer resources over this (group, bin)'s rows of X and matrix of H: anything out of range reads as zero, so
-  // neither the panel loads nor the B loads need a branch (and all of them are in flight together)
-  const BufRsrc xr = make_rsrc(a.X + (((size_t)g * nf + f) * a.mcount) * a.Kc, (unsigned)((size_t)a.mcount * a.Kc * 8));
-  const BufRsrc hr = make_rsrc(a.Hd + (((size_t)g * nf + f) * a.Kc) * a.Nc, (unsigned)((size_t)a.Kc * a.Nc * 8));
+  const int nr = ct * 16 + i16;                 // this lane's real output column inside the unit
+
+  // unit u -> (bin fastest: neighbouring workgroups read neighbouring X / Y rows; row blocks of one bin share H in L2)
+  auto decode = [&](long long u, int& g, int& f, int& nb, int& mb) {
+    f = (int)(u % nf); u /= nf;
+    mb = (int)(u % nmb); u /= nmb;
+    nb = (int)(u % nnb);
+    g = (int)(u / nnb);
+  };
+  // loads of one step: the chunk's panel rows (16 bytes per lane, rows past the slab / channels past the chunk read as
+  // zero through the buffer resource) and this lane's B values: k step kk covers the real rows
+  // k = 8 (kk / 2) + 2 kq + (kk % 2) of the chunk
+  auto issue = [&](long long u, int kc, f4 (&val)[NIT], float (&bf)[2 * K2N]) __attribute__((always_inline)) {
+    int g, f, nb, mb;
+    decode(u, g, f, nb, mb);
+    const int kc0 = kc * KCH, kch = min(KCH, a.Kc - kc0), q4 = kch / 2, row0 = mb * kDenseMB;
+    const BufRsrc xr = make_rsrc(a.X + (((size_t)g * nf + f) * a.mcount) * a.Kc, (unsigned)((size_t)a.mcount * a.Kc * 8));
+    const BufRsrc hr = make_rsrc(a.Hd + (((size_t)g * nf + f) * a.Kc) * a.Nc, (unsigned)((size_t)a.Kc * a.Nc * 8));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
+      const unsigned off = (c4 < q4 && r < kDenseMB) ? (unsigned)((((row0 + r) * a.Kc) + kc0 + 2 * c4) * 8) : 0xFFFFFFFFu;
+      val[it] = buf_load_f32x4(xr, off, 0);
+    }
+    // B values: no per-step conditions at all (hipcc turns them into branches with a full wait in front of every merge):
+    // input channels past Kc fall outside the resource by themselves (it covers exactly this bin's Kc x Nc matrix), a
+    // lane whose output column does not exist starts from an offset that is outside it for every k
+    const int o = nb * 8 * NCT + (nr >> 1), comp = nr & 1;
+    const unsigned obase = (o < a.Nc) ? (unsigned)(o * 8) : 0x80000000u;
+    const unsigned rowb = (unsigned)a.Nc * 8u;              // bytes per input channel row of H
+#pragma unroll
+    for (int kk = 0; kk < 2 * K2N; ++kk) {
+      const int k = 8 * (kk >> 1) + 2 * kq + (kk & 1);
+      const int part = kk & 1;                              // 0: times Xr, 1: times Xi (takes the other component of H)
+      const unsigned off = obase + (unsigned)(kc0 + (k >> 1)) * rowb + (unsigned)((comp ^ part) * 4);
+      bf[kk] = buf_load_f32(hr, off, 0);        // raw value: nothing may touch it here, or the wave would wait for the load
+    }
+  };
+  const float bsign = (nr & 1) ? 1.f : -1.f;     // odd k steps (times Xi) take -Hi for a real-part column, +Hr for an imaginary-part one
 
   v4f acc[MTW];
 #pragma unroll
   for (int t = 0; t < MTW; ++t) acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
-
-  for (int kc0 = 0; kc0 < a.Kc; kc0 += KCH) {
-    const int kch = min(KCH, a.Kc - kc0);                  // complex channels of this chunk (a multiple of 8)
-    // ---- A panel -> LDS (whole rows of the chunk, 16 bytes per lane; rows past the slab and channels past the
-    // chunk are zero)
-    {
-      constexpr int Q4 = KCH / 2;                          // float4 per panel row
-      constexpr int NIT = kDenseMB * Q4 / 512;
-      const int q4 = kch / 2;
-      f4 val[NIT];
+  f4 val[NIT];
+  float bnext[2 * K2N], bcur[2 * K2N];
+  long long u = blockIdx.x;
+  int kc = 0, cur = 0;
+  if (u < U) issue(u, 0, val, bnext);
+  while (u < U) {
+    int g, f, nb, mb;
+    decode(u, g, f, nb, mb);
+    const int row0 = mb * kDenseMB;
+    float* pa = pbase + cur * PANEL;
+    __syncthreads();                                       // the other panel's readers (MFMAs two steps ago, staged
+                                                           // output one step ago) are done
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
-        const unsigned off = (c4 < q4) ? (unsigned)((((row0 + r) * a.Kc) + kc0 + 2 * c4) * 8) : 0xFFFFFFFFu;
-        val[it] = buf_load_f32x4(xr, off, 0);
-      }
-      __syncthreads();                                     // (previous chunk's reads are done)
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
-        *reinterpret_cast<f4*>(pa + r * RS + 4 * c4) = val[it];
-      }
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 512 * it, r = idx / Q4, c4 = idx % Q4;
+      if (kDenseMB * Q4 % 512 == 0 || r < kDenseMB) *reinterpret_cast<f4*>(pa + r * RS + 4 * c4) = val[it];
     }
-    // (B loads come after the panel has left the registers: with both sets live the kernel needs more than the 128
-    // VGPRs that let two workgroups share a CU)
-    // ---- B fragments: step kk covers the real rows k = 8 (kk / 2) + 2 kq + (kk % 2) of the chunk
-    float bfrag[2 * K2N];
 #pragma unroll
-    for (int kk = 0; kk < 2 * K2N; ++kk) {
-      const int k = 8 * (kk >> 1) + 2 * kq + (kk & 1);
-      const int i = kc0 + (k >> 1), part = k & 1;          // complex input channel; 0: times Xr, 1: times Xi
-      const unsigned off = (col_ok && (k >> 1) < kch) ? (unsigned)(((i * a.Nc + o) * 2 + (comp ^ part)) * 4) : 0xFFFFFFFFu;
-      const float hv = buf_load_f32(hr, off, 0);
-      bfrag[kk] = (part == 1 && comp == 0) ? -hv : hv;
-    }
+    for (int kk = 0; kk < 2 * K2N; ++kk) bcur[kk] = (kk & 1) ? bsign * bnext[kk] : bnext[kk];
     __syncthreads();
+    // ---- next step's loads travel while this step multiplies
+    long long un = u;
+    int kcn = kc + 1;
+    if (kcn == nkc) { kcn = 0; un = u + gridDim.x; }
+    if (un < U) issue(un, kcn, val, bnext);
 #pragma unroll
     for (int t = 0; t < MTW; ++t) {
       const int mt = ms + MS * t;
       if (row0 + mt * 16 < a.mcount) {                     // (wave-uniform: whole row tiles past the slab are skipped)
         const float* prow = pa + (mt * 16 + i16) * RS + 2 * kq;
         v4f c = acc[t];
+        // the whole row tile's A values are requested first (plain ds_read_b64 through asm: left to hipcc the reads
+        // sink next to their MFMAs, one full LDS latency per four of them)
+        constexpr int GS = (kDenseMB >= 128 || K2N <= 8) ? K2N : K2N / 2;   // (the small unit has 128 VGPRs: half rows at a time)
+        static_for<0, K2N / GS>([&](auto gc) {
+          constexpr int k0 = GS * decltype(gc)::value;
+          f2 av[GS];
+          lds_read_strided<GS, 4>(av, reinterpret_cast<const f2*>(prow + 8 * k0));
+          lds_arrive(av);
 #pragma unroll
-        for (int k2 = 0; k2 < K2N; ++k2) {
-#if defined(FC_DENSE_DBG) && FC_DENSE_DBG == 1      // diagnostic build: no LDS reads in the k loop
-          const f2 av = mk2(bfrag[0], bfrag[1]);
-#else
-          const f2 av = *reinterpret_cast<const f2*>(prow + 8 * k2);
-#endif
-#if defined(FC_DENSE_DBG) && FC_DENSE_DBG == 2      // diagnostic build: no MFMA
-          c[k2 & 3] += av.x * bfrag[2 * k2] + av.y * bfrag[2 * k2 + 1];
-#else
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bfrag[2 * k2], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bfrag[2 * k2 + 1], c, 0, 0, 0);
-#endif
-        }
+          for (int k2 = 0; k2 < GS; ++k2) {
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k2].x, bcur[2 * (k0 + k2)], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k2].y, bcur[2 * (k0 + k2) + 1], c, 0, 0, 0);
+          }
+        });
         acc[t] = c;
       }
     }
-  }
-  // ---- store: register r of row tile mt is row 16 mt + 4 (lane / 16) + r, this lane's column.  The tiles go through
-  // the (now free) panel area so that whole rows of the block leave in 16-byte pieces: written straight from the
-  // accumulators they are 4-byte stores in 64-byte runs, and the kernel spent two thirds of its time on them.
-  constexpr int NCOL = 16 * NCT;                 // real columns of the block
-  constexpr int OS = NCOL + 4;                   // LDS row pitch of the output block (floats)
-  __syncthreads();                               // every wave is done reading the panel
+    if (kc == nkc - 1) {
+      // ---- unit done: register r of row tile mt is row 16 mt + 4 (lane / 16) + r, this lane's column.  The tiles go
+      // through the OTHER panel (free until the top of the next step) so that whole rows leave in 16-byte pieces.
+      float* po = pbase + (cur ^ 1) * PANEL;
 #pragma unroll
-  for (int t = 0; t < MTW; ++t) {
-    const int mt = ms + MS * t;
+      for (int t = 0; t < MTW; ++t) {
+        const int mt = ms + MS * t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pa[(mt * 16 + 4 * kq + r) * OS + nr] = acc[t][r];
-  }
-  __syncthreads();
-  {
-    constexpr int Q4 = NCOL / 4;                 // float4 per output row of the block
-    float* yf = reinterpret_cast<float*>(a.Y + (((size_t)g * nf + f) * a.mcount) * a.Nc) + (size_t)nb * NCOL;
-    const int ncol_ok = min(NCOL, 2 * a.Nc - nb * NCOL);      // real columns that exist (a multiple of 16)
-    for (int idx = tid; idx < kDenseMB * Q4; idx += 512) {
-      const int r = idx / Q4, c4 = idx % Q4;
-      if (row0 + r < a.mcount && 4 * c4 < ncol_ok)
-        *reinterpret_cast<f4*>(yf + (size_t)(row0 + r) * (2 * a.Nc) + 4 * c4) = *reinterpret_cast<const f4*>(pa + r * OS + 4 * c4);
+        for (int r = 0; r < 4; ++r) po[(mt * 16 + 4 * kq + r) * OS + nr] = acc[t][r];
+        acc[t] = v4f{0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();
+      constexpr int O4 = NCOL / 4;                         // float4 per output row of the unit
+      float* yf = reinterpret_cast<float*>(a.Y + (((size_t)g * nf + f) * a.mcount) * a.Nc) + (size_t)nb * NCOL;
+      const int ncol_ok = min(NCOL, 2 * a.Nc - nb * NCOL);  // real columns that exist (a multiple of 16)
+      for (int idx = tid; idx < kDenseMB * O4; idx += 512) {
+        const int r = idx / O4, c4 = idx % O4;
+        if (row0 + r < a.mcount && 4 * c4 < ncol_ok)
+          *reinterpret_cast<f4*>(yf + (size_t)(row0 + r) * (2 * a.Nc) + 4 * c4) = *reinterpret_cast<const f4*>(po + r * OS + 4 * c4);
+      }
     }
+    u = un; kc = kcn; cur ^= 1;
   }
 }
 

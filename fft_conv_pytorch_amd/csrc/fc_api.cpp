@@ -160,6 +160,7 @@ struct fc_plan {
   int wide;                   // > 8 input channels per group on the batch-sharing work list (conv1d_wide.hpp)
   int dense;                  // >= 16 channels per group on both sides: spectra through HBM + MFMA contraction (dense1d.hpp)
   int dense_mslab;            // rows (batch x tiles) per slab of that pipeline's workspace
+  int dense_cus;              // CUs of the plan's device (grid of its persistent GEMM)
   size_t dense_pers_bytes;    // its kernel spectrum before the bin-major re-layout (scratch of fc_transform_kernel)
   int nseg, seg_taps;         // 1-D: the kernel runs in nseg segments of seg_taps taps (1 = whole kernel)
   int64_t kd_plan;            // dilated extent the tiles are planned for (of one segment)
@@ -373,6 +374,8 @@ static int plan_1d_inner(fc_plan* p) {
     slab = std::max<int64_t>(128, slab);
     if (const char* e = getenv("FFTCONV_DENSE_SLAB")) slab = std::max(1, atoi(e));     // testing knob: rows per slab
     p->dense_mslab = (int)std::min<int64_t>(M, slab);
+    p->dense_cus = 256;
+    if (!current_device_cus(&p->dense_cus)) return fail(FC_ERR_HIP, "cannot query the current device");
     p->workspace_bytes = std::max(row_bytes * (size_t)p->dense_mslab, p->dense_pers_bytes);
     p->pers_nb = 0; p->d_items = nullptr; p->pers_items = 0; p->pers_grid = 0;
     return FC_OK;
@@ -994,6 +997,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.Cig = p.Cig; a.Cog = p.Cog; a.Kc = p.Cig_pad; a.Nc = p.Cog_pad;
     a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode;
     a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
+    a.cus = p.dense_cus;
     const int64_t M = p.d.batch * (int64_t)p.ntiles;
     for (int64_t m0 = 0; m0 < M; m0 += p.dense_mslab) {
       a.m0 = (int)m0; a.mcount = (int)std::min<int64_t>(p.dense_mslab, M - m0);

@@ -295,22 +295,27 @@ hipError_t dense_dispatch(int which, const DenseArgs& a, hipStream_t st) {
   const int nf = kT / 2 + 1;
   const int nct = a.Nc >= 64 ? 8 : (a.Nc >= 32 ? 4 : 2);
   const int k2n = a.Kc <= 16 ? 4 : (a.Kc <= 32 ? 8 : 16);
-  const size_t lds = (size_t)kDenseMB * std::max(8 * k2n + 4, 16 * nct + 4) * sizeof(float);   // panel / output block
-  const long long nmb = (a.mcount + kDenseMB - 1) / kDenseMB, nnb = (a.Nc + 8 * nct - 1) / (8 * nct);
-  const long long grid = nmb * nnb * nf * a.G;
-  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-#define FC_DENSE_GEMM(N, K)                                                      \
-  if (nct == N && k2n == K) {                                                    \
+  const int mbr = (a.mcount <= 64 && nct >= 4) ? 32 : 128;                    // rows per unit
+  const size_t lds = 2 * (size_t)mbr * std::max(8 * k2n + 4, 16 * nct + 4) * sizeof(float);   // two panels (each also holds an output block)
+  const long long nmb = (a.mcount + mbr - 1) / mbr, nnb = (a.Nc + 8 * nct - 1) / (8 * nct);
+  const long long units = nmb * nnb * nf * a.G;
+  // persistent: one workgroup per CU (two with the small unit)
+  const long long grid = std::min<long long>(units, (long long)std::max(1, a.cus) * (mbr == 32 ? 2 : 1));
+  if (grid <= 0 || units > 0x7fffffffffffLL) return hipErrorInvalidValue;
+#define FC_DENSE_GEMM(N, K, MBR)                                                 \
+  if (nct == N && k2n == K && mbr == MBR) {                                      \
     static LdsOptIn done;                                                        \
-    auto k = dense_gemm_kernel<N, K>;                                            \
+    auto k = dense_gemm_kernel<N, K, MBR>;                                       \
     hipError_t e = ensure_lds(k, lds, &done);                                    \
     if (e != hipSuccess) return e;                                               \
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, st, a, nf);      \
     return hipGetLastError();                                                    \
   }
-  FC_DENSE_GEMM(8, 16) FC_DENSE_GEMM(8, 8) FC_DENSE_GEMM(8, 4)
-  FC_DENSE_GEMM(4, 16) FC_DENSE_GEMM(4, 8) FC_DENSE_GEMM(4, 4)
-  FC_DENSE_GEMM(2, 16) FC_DENSE_GEMM(2, 8) FC_DENSE_GEMM(2, 4)
+  FC_DENSE_GEMM(8, 16, 128) FC_DENSE_GEMM(8, 8, 128) FC_DENSE_GEMM(8, 4, 128)
+  FC_DENSE_GEMM(4, 16, 128) FC_DENSE_GEMM(4, 8, 128) FC_DENSE_GEMM(4, 4, 128)
+  FC_DENSE_GEMM(2, 16, 128) FC_DENSE_GEMM(2, 8, 128) FC_DENSE_GEMM(2, 4, 128)
+  FC_DENSE_GEMM(8, 16, 32) FC_DENSE_GEMM(8, 8, 32) FC_DENSE_GEMM(8, 4, 32)
+  FC_DENSE_GEMM(4, 16, 32) FC_DENSE_GEMM(4, 8, 32) FC_DENSE_GEMM(4, 4, 32)
 #undef FC_DENSE_GEMM
   return hipErrorInvalidValue;
 }

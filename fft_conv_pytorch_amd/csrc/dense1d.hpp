@@ -129,12 +129,23 @@ __global__ __launch_bounds__(NT) void dense_inv_kernel(const DenseArgs a) {
     constexpr int NFS = NT / NSEQ;
     const bool ld_ok = 2 * (cb * NSEQ + s) < a.Nc;
     f2* z = lds + s * LSEQP;
-    const f4* in = reinterpret_cast<const f4*>(a.Y + (((size_t)g * NF) * a.mcount + ml) * a.Nc + 2 * (cb * NSEQ + s));
-    const size_t fstride = (size_t)a.mcount * a.Nc / 2;
-    if (ld_ok) {
-      for (int f = fsub; f < NF; f += NFS) {
-        const f4 yv = in[(size_t)f * fstride];
-        const f2 ya = mk2(yv.x, yv.y), yb = mk2(yv.z, yv.w);
+    // all of a lane's bins are requested before the first one is used (as a loop of load -> re-pack -> LDS store the
+    // gather paid one memory latency per bin: 17 in a row); bins past T/2 and idle pairs read outside the resource
+    constexpr int NITER = (NF + NFS - 1) / NFS;
+    const BufRsrc yr = make_rsrc(a.Y + ((size_t)g * NF) * a.mcount * a.Nc, (unsigned)((size_t)NF * a.mcount * a.Nc * 8));
+    const unsigned base = (unsigned)(((size_t)ml * a.Nc + 2 * (cb * NSEQ + s)) * 8);
+    const unsigned fstride = (unsigned)((size_t)a.mcount * a.Nc * 8);
+    f4 yv[NITER];
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+      const int f = fsub + NFS * it;
+      yv[it] = buf_load_f32x4(yr, (ld_ok && f < NF) ? base + (unsigned)f * fstride : 0xFFFFFFFFu, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NITER; ++it) {
+      const int f = fsub + NFS * it;
+      if (ld_ok && f < NF) {
+        const f2 ya = mk2(yv[it].x, yv[it].y), yb = mk2(yv[it].z, yv[it].w);
         z[G::nat(f)] = add_pi(ya, yb);
         if (f != 0 && f != T / 2) z[G::nat(T - f)] = conj_add_iconj(ya, yb);
       }
@@ -148,14 +159,43 @@ __global__ __launch_bounds__(NT) void dense_inv_kernel(const DenseArgs a) {
     const int t0 = tile * a.V;
     const int limit = min(a.V, a.Lfull - t0);
     const int nbase = o1 + P * P * j;
-    float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase);
-    float* y1 = y0 + a.Lout;
+    if constexpr (S == 1) {
+      // as in conv1d_pers: rows below the last fully valid row ka in blocks of 8 behind one scalar branch, the block
+      // that holds row ka with per-row tests and an out-of-range offset for lanes past the window; channels that do
+      // not exist (padding of the pair) start from an offset outside the resource
+      const int ka = limit >= P ? (limit - P) / P + 1 : 0;
+      const BufRsrc yr = make_rsrc(a.y + ((size_t)b * a.Cout + (size_t)g * a.Cog) * a.Lout, (unsigned)((size_t)a.Cog * a.Lout * 4));
+      const unsigned vo = (unsigned)(((size_t)co0 * a.Lout + (size_t)(t0 + nbase)) * 4);
+      const unsigned vo0 = ok0 ? vo : 0x80000000u, vo1 = ok1 ? vo + (unsigned)a.Lout * 4u : 0x80000000u;
+      static_for<0, P / 8>([&](auto bc) {
+        constexpr int k0 = 8 * decltype(bc)::value;
+        if (ka >= k0 + 8) {
+          static_for<k0, k0 + 8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            buf_store_f32(v[k].x + bias0, yr, vo0, P * k * 4);
+            buf_store_f32(v[k].y + bias1, yr, vo1, P * k * 4);
+          });
+        } else if (ka >= k0) {
+          static_for<k0, k0 + 8>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (k <= ka) {
+              const unsigned dead = (nbase + P * k < limit) ? 0u : 0x80000000u;
+              buf_store_f32(v[k].x + bias0, yr, vo0 | dead, P * k * 4);
+              buf_store_f32(v[k].y + bias1, yr, vo1 | dead, P * k * 4);
+            }
+          });
+        }
+      });
+    } else {
+      float* y0 = a.y + ((size_t)b * a.Cout + cg0) * a.Lout + (size_t)(t0 + nbase);
+      float* y1 = y0 + a.Lout;
 #pragma unroll
-    for (int k = 0; k < P; ++k)
-      if (nbase + P * k < limit) {
-        if (ok0) y0[P * k] = v[k].x + bias0;
-        if (ok1) y1[P * k] = v[k].y + bias1;
-      }
+      for (int k = 0; k < P; ++k)
+        if (nbase + P * k < limit) {
+          if (ok0) y0[P * k] = v[k].x + bias0;
+          if (ok1) y1[P * k] = v[k].y + bias1;
+        }
+    }
   }
 }
 

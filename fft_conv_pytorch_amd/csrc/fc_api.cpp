@@ -272,19 +272,21 @@ static int plan_1d_inner(fc_plan* p) {
     // FFTCONV_DENSE=0 keeps the fused kernels (A/B runs).
     const char* env = getenv("FFTCONV_DENSE");
     const int want_dense = env ? atoi(env) : 1;
-    const fc::TileImpl* dt = find_tile(1024);
-    // Measured against the fused kernels (scripts/dense_check.py, us): 128->96 M = 30 rows 76 / 175; 32->32 M = 144
-    // 57 / 82; 64->64 M = 152 124 / 152; but 24->40 M = 18 44 / 33, 16->24 x 2 groups M = 26 41 / 27, 16->16 M = 2
-    // 31 / 23: three launches need work to amortise -- at least 32 channels a side and 64 K row-channel products.
-    // FFTCONV_DENSE=2 forces the pipeline for every shape it can run (tests).
+    // Measured against the fused kernels (scripts/dense_check.py, us): 128->96 M = 30 rows 58 / 175; 32->32 M = 144
+    // 50 / 84; 64->64 M = 152 91 / 150; but (first build) 24->40 M = 18 44 / 33, 16->24 x 2 groups M = 26 41 / 27,
+    // 16->16 M = 2 31 / 23: three launches need work to amortise -- at least 32 channels a side and 64 K row-channel
+    // products.  FFTCONV_DENSE=2 forces the pipeline for every shape it can run (tests).
     const int64_t Kd_d = p->kd[0];
-    const int64_t Md = d.batch * ((p->Lf[0] + (1025 - Kd_d) - 1) / std::max<int64_t>(1, 1025 - Kd_d));
+    const int dT = Kd_d <= 769 ? 1024 : 2048;             // (at least a quarter of the tile valid)
+    const fc::TileImpl* dt = find_tile(dT);
+    const int64_t Vd = std::max<int64_t>(1, dT + 1 - Kd_d);
+    const int64_t Md = d.batch * ((p->Lf[0] + Vd - 1) / Vd);
     const bool pays = want_dense == 2 || (p->Cig >= 32 && p->Cog >= 32 && Md * p->Cig * p->Cog >= 65536);
     if (want_dense && pays && dt && dt->dense && p->nseg == 1 && p->CB == 8 && p->Cig >= 16 && p->Cog >= 16 && d.stride[0] == 1 &&
-        p->up[0] == 1 && !p->diag && !p->bd_gs && Kd <= 769 && (!forced_tile || forced_tile == 1024) &&
+        p->up[0] == 1 && !p->diag && !p->bd_gs && Kd <= 1537 && (!forced_tile || forced_tile == dT) &&
         (int64_t)p->Cig * d.spatial[0] * 4 < ((int64_t)1 << 32)) {
       p->dense = 1;
-      forced_tile = 1024;
+      forced_tile = dT;
     }
   }
   if (!p->dense) {

@@ -262,11 +262,11 @@ hipError_t wgrad_diag_dispatch(const WGradArgs& a, int grid, hipStream_t st) {
 constexpr int kWgradNb = 0;
 #endif
 
-#if FC_P == 32 && FC_S == 1
-// many-channel pipeline: channel pairs per workgroup in the two transform kernels
+#if FC_P == 32 && (FC_S == 1 || FC_S == 2)
+// many-channel pipeline (1024 and 2048 tiles): channel pairs per workgroup in the two transform kernels
 #ifndef FC_DENSE_NSEQ
-#define FC_DENSE_NSEQ 8      // measured 64->64, B 8, L 16384, k 129: forward 21.1 / inverse 33.6 us at 8 (256 threads, two
-#endif                       // workgroups per CU), 24.0 / 35.3 us at 16 (512 threads, one per CU)
+#define FC_DENSE_NSEQ 8      // measured 64->64, B 8, L 16384, k 129 (1024 tile): forward 21.1 / inverse 33.6 us at 8 (256 threads,
+#endif                       // two workgroups per CU), 24.0 / 35.3 us at 16 (512 threads, one per CU); 2048 tile: 8 x 64 threads
 constexpr int kDenseNseq = FC_DENSE_NSEQ;
 hipError_t dense_dispatch(int which, const DenseArgs& a, hipStream_t st) {
   constexpr int NT = kDenseNseq * GG::TS;
@@ -345,7 +345,7 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
                                 nullptr, nullptr,
 #endif
                                 kWgradNb,
-#if FC_P == 32 && FC_S == 1
+#if FC_P == 32 && (FC_S == 1 || FC_S == 2)
                                 dense_dispatch, dense_spec_dispatch
 #else
                                 nullptr, nullptr

@@ -18,6 +18,7 @@ SHAPES = [  # batch, cin, cout, groups, L, k, kwargs
     (1, 16, 16, 1, 1200, 200, dict(padding=3)),
     (5, 128, 96, 1, 4096, 257, dict(padding=128)),
     (16, 32, 32, 1, 8192, 65, {}),
+    (4, 32, 32, 1, 65536, 1025, {}),           # 2048 tile
     (8, 64, 64, 8, 16384, 129, {}),          # 8 per group: stays on the fused kernel
 ]
 

@@ -39,6 +39,8 @@ CASES = [
     (5, 17, 19, 1, 1500, 31, True, dict(padding=15, padding_mode="replicate")),   # odd channel counts: padded to 24 / 24
     (40, 32, 32, 1, 4096, 65, True, {}),                                        # M = 200 rows: two row blocks
     (2, 80, 72, 1, 1024, 769, False, dict(padding=400)),                        # the longest kernel the 1024 tile takes
+    (3, 32, 40, 1, 6000, 1025, True, dict(padding=512)),                        # 2048 tile (lane-split transforms)
+    (2, 48, 32, 2, 5000, 385, True, dict(dilation=4, padding=100, padding_mode="reflect")),   # dilated extent 1537: its longest
 ]
 
 

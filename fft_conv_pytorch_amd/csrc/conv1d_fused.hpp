@@ -38,6 +38,7 @@ struct Conv1dArgs {
   int L, pad, pad_mode;  // source row length, left padding (may be negative for a transposed plan)
   int up;                // transposed plan: the source is spread over a grid of this step (zeros between)
   int ph;                // batch-sharing kernel: dilation run as `ph` interleaved phases (virtual batch B*ph), else 1
+  int ph2;               // batch-sharing kernel: the phases run in pairs (conv1d_pers.hpp PH2; ph even, slots = batch items)
   int diag;              // batch-sharing kernel: depthwise plan (8-channel blocks, per-channel mix, [pair][T/2] spectrum)
   int slot_tiles;        // batch-sharing kernel: the slots of a work item are consecutive TILES of one (virtual) batch
                          // item instead of consecutive batch items of one tile

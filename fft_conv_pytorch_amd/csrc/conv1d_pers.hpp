@@ -42,8 +42,13 @@ __device__ __forceinline__ void stamp_clock(unsigned long long* buf, int item, i
     buf[((size_t)item * 16 + (threadIdx.x >> 6)) * 16 + slot] = __builtin_amdgcn_s_memtime();
 }
 
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false>
+// PH2 (with PHASES, an even number of phases): the two sequences of a wave are the phases 2j and 2j+1 of ONE channel
+// pair instead of two channel pairs of one phase, so that a lane can load / store both phases' samples of a position
+// as 8 bytes and trade halves with its partner lane (v_permlane32_swap): half the memory instructions, each
+// touching half the cache lines of the 4-byte accesses at a 4*d-byte pitch.
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false, bool PH2 = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
+  static_assert(!PH2 || (PHASES && !DIAG && !SEG && S == 1 && CIB == 8), "paired phases: plain phase build on a P*P tile");
   using G = Geo<P, S>;
   constexpr int T = G::T;
   constexpr int NPI = CIB / 2;
@@ -62,10 +67,14 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const int sq = tid / G::TS;               // sequence slot: batch slot nb, channel pair p
   const int tseq = tid % G::TS;
   static_assert(G::TS <= 64 && (NPI * G::TS) % 64 == 0, "a batch slot is a whole number of wavefronts");
-  const int nb = __builtin_amdgcn_readfirstlane(tid / (NPI * G::TS)), pr = sq % NPI;   // batch slot: wave-uniform
+  // batch slot and channel pair of this thread's sequence: slot wave-uniform, except with PH2 where the two halves of
+  // a wave are slots 2j and 2j+1 (even / odd phase) of pair wave % 4
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = PH2 ? 2 * (wv / NPI) + ((tid >> 5) & 1) : __builtin_amdgcn_readfirstlane(tid / (NPI * G::TS));
+  const int pr = PH2 ? wv % NPI : sq % NPI;
   f2* twl = lds;
-  f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ]
-  f2* zseq = zbuf + sq * G::LSEQ;
+  f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ], sequence (slot, pair) at slot * NPI + pair
+  f2* zseq = zbuf + (nb * NPI + pr) * G::LSEQ;
 
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
@@ -93,6 +102,28 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const bool has1 = act_in && ci0 + 1 < a.Cig && (!DIAG || g * CIB + ci0 + 1 < a.Cin);
     const unsigned ro0 = ((unsigned)(b - bfirst) * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
     const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
+    if constexpr (PH2) {
+      // even slot of this wave (wave-uniform), its batch item and (even) phase; the odd slot is the next phase
+      const int vbA = wi.b0 + 2 * (wv / NPI), bA = vbA / nph, phA = vbA - bA * nph;
+      const int posA = wi.tile * a.V * nph + phA - a.pad;
+      const bool both_in = (posA >= 0) && (posA + 1 + (T - 1) * nph < a.L);
+      if (both_in && __all(has1)) {
+        // lane L of the wave asks for (phase, phase + 1) at the positions 64 m + L, m = 0 .. P/2 - 1; the swap hands
+        // lanes 0-31 (even phase) the even-phase halves of both lane groups and lanes 32-63 the odd-phase halves:
+        // rows n1 = 2m and 2m + 1 of this thread's sequence
+        const unsigned rA = ((unsigned)(bA - bfirst) * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
+        const unsigned q0 = rA + (unsigned)(posA + (tid & 63) * nph) * 4u, q1 = q0 + (unsigned)a.L * 4u;
+        const unsigned step2 = 256u * (unsigned)nph;
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) {
+          f2 cx = buf_load_f32x2(xg, q0, step2 * m), cy = buf_load_f32x2(xg, q1, step2 * m);
+          v[2 * m].x = cx.x; v[2 * m + 1].x = cx.y; v[2 * m].y = cy.x; v[2 * m + 1].y = cy.y;
+        }
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) { swap_halves_c<0>(v[2 * m], v[2 * m + 1]); swap_halves_c<1>(v[2 * m], v[2 * m + 1]); }
+        return;
+      }
+    }
     if (interior && has1 && !PHASES) {
       const unsigned v0 = ro0 + (unsigned)(pos0 + tseq) * 4u, v1 = ro1 + (unsigned)(pos0 + tseq) * 4u;
 #pragma unroll
@@ -383,6 +414,40 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
         for (int k = 0; k < P; ++k)
           if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
+      } else if constexpr (PH2) {
+        // both phases of a position leave as 8 bytes: rows 2m and 2m + 1 trade halves so that lane L holds (even
+        // phase, odd phase) of sample 64 m + L.  The odd phase may be one sample shorter at the very end of a row.
+        const int vbA = wi.b0 + 2 * (wv / NPI), bA = vbA / nph, phA = vbA - bA * nph;
+        const int limA = min(a.V, (a.Lfull - phA + nph - 1) / nph - t0), limB = min(a.V, (a.Lfull - phA - 1 + nph - 1) / nph - t0);
+        const BufRsrc yr = make_rsrc(a.y + ((size_t)bA * a.Cout + (size_t)(g * a.Cog + oc * a.cob)) * a.Lout, (unsigned)((size_t)a.cob * a.Lout * 4));
+        const int L64 = tid & 63;
+        const unsigned w0 = (unsigned)(((size_t)(2 * pr) * a.Lout + (size_t)(t0 + L64) * nph + phA) * 4), w1 = w0 + (unsigned)a.Lout * 4u;
+        const unsigned step2 = 256u * (unsigned)nph;
+        const int mfull = limB >= 64 ? (limB - 64) / 64 + 1 : 0;        // rows m below it: every lane valid in both phases
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) { swap_halves_c<0>(v[2 * m], v[2 * m + 1]); swap_halves_c<1>(v[2 * m], v[2 * m + 1]); }
+        static_for<0, P / 8>([&](auto bc) {
+          constexpr int m0 = 4 * decltype(bc)::value;
+          if (mfull >= m0 + 4) {
+            static_for<m0, m0 + 4>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              buf_store_f32x2(mk2(v[2 * m].x + bias0, v[2 * m + 1].x + bias0), yr, w0, step2 * m);
+              buf_store_f32x2(mk2(v[2 * m].y + bias1, v[2 * m + 1].y + bias1), yr, w1, step2 * m);
+            });
+          } else if (64 * m0 < limA) {
+            static_for<m0, m0 + 4>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              if (64 * m < limA) {
+                const int n = 64 * m + L64;
+                const unsigned dA = n < limA ? 0u : 0x80000000u, dB = n < limB ? 0u : 0x80000000u;
+                buf_store_f32(v[2 * m].x + bias0, yr, w0 | dA, step2 * m);
+                buf_store_f32(v[2 * m + 1].x + bias0, yr, (w0 + 4u) | dB, step2 * m);
+                buf_store_f32(v[2 * m].y + bias1, yr, w1 | dA, step2 * m);
+                buf_store_f32(v[2 * m + 1].y + bias1, yr, (w1 + 4u) | dB, step2 * m);
+              }
+            });
+          }
+        });
       } else {
         const int ystep = P * nph;
 #pragma unroll

@@ -170,6 +170,7 @@ struct fc_plan {
   int G;                      // channel groups as the 1-D kernels see them (C/8 blocks for a depthwise plan)
   int slot_tiles;             // work-item slots = consecutive tiles of one batch item (else consecutive batch items)
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
+  int ph2;                    // the phases run in pairs (conv1d_pers.hpp PH2)
   fc::WorkItem* d_items;
 };
 
@@ -544,6 +545,13 @@ static int plan_1d_persistent(fc_plan* p) {
   FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
   FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;
+  {
+    // phases in pairs: an even number of phases, slots = batch items (so slots 2j, 2j+1 are neighbouring phases of one
+    // batch item), plain dense-block kernel on a P*P tile; FFTCONV_PH2=0 keeps the 4-byte accesses (A/B runs, tests)
+    const char* env = getenv("FFTCONV_PH2");
+    p->ph2 = (!env || atoi(env) != 0) && p->ph > 1 && p->ph % 2 == 0 && !p->slot_tiles && !p->diag && !p->wide && p->nseg == 1 &&
+             nb >= 2 && t->S == 1;
+  }
   return FC_OK;
 }
 
@@ -1018,6 +1026,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.B = (int)p.d.batch; a.Cin = (int)p.d.in_channels; a.Cout = (int)p.d.out_channels; a.G = p.G;
     a.Cig = p.Cig; a.Cog = p.Cog; a.Cig_pad = p.Cig_pad; a.Cog_pad = p.Cog_pad; a.cob = p.cob; a.n_ochunks = p.n_ochunks;
     a.L = (int)p.d.spatial[0]; a.pad = p.padl[0]; a.pad_mode = p.d.padding_mode; a.up = p.up[0]; a.ph = p.ph; a.slot_tiles = p.slot_tiles; a.diag = p.diag;
+    a.ph2 = p.ph2;
     a.Kd = (int)p.kd[0]; a.V = p.V; a.ntiles = p.ntiles; a.Lfull = p.Lfull; a.Lout = (int)p.out_sp[0];
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;

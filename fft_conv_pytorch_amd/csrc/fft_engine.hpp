@@ -185,6 +185,22 @@ __device__ __forceinline__ f4 buf_load_f32x4(BufRsrc r, unsigned voff, unsigned 
   return o;
 }
 
+__device__ __forceinline__ void buf_store_f32x2(f2 v, BufRsrc r, unsigned voff, unsigned soff) {
+  u32x2 d; d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(d, r, voff, soff, 0);
+}
+// v_permlane32_swap (gfx950): lanes 32-63 of `a` trade places with lanes 0-31 of `b`
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
+}
+// the same on one component (0 = x, 1 = y) of two packed complex values
+template <int C>
+__device__ __forceinline__ void swap_halves_c(f2& a, f2& b) {
+  float fa = C ? a.y : a.x, fb = C ? b.y : b.x;
+  swap_halves(fa, fb);
+  if (C) { a.y = fa; b.y = fb; } else { a.x = fa; b.x = fb; }
+}
 __device__ __forceinline__ void buf_store_f32(float v, BufRsrc r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
 }

@@ -482,3 +482,41 @@ def test_float64_tensors_direct_kernel():
         y = fn(torch.from_numpy(xg).double().to(DEV), torch.from_numpy(wg).double().to(DEV),
                bias=torch.from_numpy(bg).double().to(DEV), **gu.g5_kwargs(kind, meta))
         gu.check_entry(y.cpu().numpy(), gold["y"], 2e-6)
+
+
+# ----------------------------------------------------------------------------- dilation phases in pairs (8-byte accesses)
+def test_paired_dilation_phases_match_single_phases(monkeypatch):
+    """An even dilation runs its phases in pairs on the batch-sharing kernel: a lane loads / stores both phases of a
+    position as 8 bytes and trades halves with its partner lane (v_permlane32_swap).  Against the one-phase-per-slot
+    build (FFTCONV_PH2=0) and torch, for row ends where the odd phase is one sample shorter, odd paddings (unaligned
+    8-byte accesses), every padding mode (border tiles take the per-sample path), groups and both work-item sizes."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(2024)
+    cases = [  # batch, channels, groups, L, k, dilation, padding, mode
+        (8, 8, 1, 40001, 129, 4, 0, "constant"),        # Lfull odd: phase lengths differ
+        (4, 16, 2, 30000, 257, 2, 255, "constant"),     # odd padding
+        (3, 8, 1, 20011, 65, 6, 33, "reflect"),
+        (5, 8, 1, 9000, 33, 4, 64, "circular"),
+        (2, 24, 3, 70000, 200, 2, 7, "replicate"),
+        (16, 8, 1, 5000, 17, 4, 3, "constant"),          # short rows: mostly border tiles
+    ]
+    for B, C, g, L, k, dil, pad, mode in cases:
+        x = torch.randn(B, C, L, generator=gen).to(DEV)
+        w = (torch.randn(C, C // g, k, generator=gen) / math.sqrt(C // g * k)).to(DEV)
+        b = torch.randn(C, generator=gen).to(DEV)
+        outs = {}
+        for ph2 in ("1", "0"):
+            monkeypatch.setenv("FFTCONV_PH2", ph2)       # (read at plan creation)
+            _native.clear_plan_cache()
+            outs[ph2] = fft_conv(x, w, b, padding=pad, padding_mode=mode, dilation=dil, groups=g)
+        xd = x.double()
+        if mode != "constant" and pad:
+            xd = F.pad(xd, (pad, pad), mode=mode)
+            want = F.conv1d(xd, w.double(), b.double(), dilation=dil, groups=g)
+        else:
+            want = F.conv1d(xd, w.double(), b.double(), padding=pad, dilation=dil, groups=g)
+        assert _rel(outs["1"], want) < REL_TOL, (B, C, g, L, k, dil, pad, mode)
+        assert _rel(outs["0"], want) < REL_TOL
+    monkeypatch.delenv("FFTCONV_PH2", raising=False)
+    _native.clear_plan_cache()

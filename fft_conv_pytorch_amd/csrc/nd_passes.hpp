@@ -259,11 +259,25 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
 
   f2 v[P];
   {
-    const f2* s = a.src + (size_t)img * a.sa + (size_t)c * a.sc + (size_t)(bn0 + sq) * a.sb;
+    // (buffer loads: samples past NLEN and idle sequences read as zero without a branch per load -- with branches hipcc
+    // waits for every load before the next one)
+    const f2* s0 = a.src + (size_t)img * a.sa + (size_t)c * a.sc + (size_t)bn0 * a.sb;
+    const long long span = (long long)(min(NSEQ, a.NB - bn0) - 1) * a.sb + a.NLEN;      // complex values reachable from s0
+    if (span > 0 && span * 8 < 0x7fffffffLL && a.sb >= 0) {
+      const BufRsrc sr = make_rsrc(s0, (unsigned)(span * 8));
+      const unsigned rowoff = act ? (unsigned)((long long)sq * a.sb * 8) : 0x80000000u;
 #pragma unroll
-    for (int n1 = 0; n1 < P; ++n1) {
-      const int n = G::N2 * n1 + tseq;
-      v[n1] = (act && n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int n = G::N2 * n1 + tseq;
+        v[n1] = buf_load_f32x2(sr, n < a.NLEN ? rowoff + (unsigned)n * 8u : 0xFFFFFFFFu, 0);
+      }
+    } else {
+      const f2* s = s0 + (size_t)sq * a.sb;
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int n = G::N2 * n1 + tseq;
+        v[n1] = (act && n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
+      }
     }
   }
   fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, act, twA, twB);
@@ -311,10 +325,30 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   f2 wtw[P];
   passA_twiddle_fetch<G>(wtw, tseq, twA);      // requested first: lands while the spectra are loaded
   {
+    // every bin of this thread is requested before the first is stored to LDS (as a loop of load -> store the gather
+    // paid one memory latency per iteration); sequences past NB read as zero through the buffer resource
     const f2* in = a.src + (size_t)img * a.sa + (size_t)c * a.sc + bn0;
-    for (int idx = tid; idx < T * NSEQ; idx += NT) {
-      const int r = idx % NSEQ, f = idx / NSEQ;
-      lds[r * LSEQP + G::nat(f)] = (bn0 + r < a.NB) ? in[(size_t)f * a.sb + r] : mk2(0.f, 0.f);
+    static_assert((T * NSEQ) % NT == 0, "whole rounds of the gather");
+    constexpr int NITER = T * NSEQ / NT;
+    const long long span = (long long)(T - 1) * a.sb + min(NSEQ, a.NB - bn0);
+    if (span > 0 && span * 8 < 0x7fffffffLL && a.sb >= 0) {
+      const BufRsrc sr = make_rsrc(in, (unsigned)(span * 8));
+      f2 val[NITER];
+#pragma unroll
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = tid + u * NT, r = idx % NSEQ, f = idx / NSEQ;
+        val[u] = buf_load_f32x2(sr, bn0 + r < a.NB ? (unsigned)(((long long)f * a.sb + r) * 8) : 0xFFFFFFFFu, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = tid + u * NT, r = idx % NSEQ, f = idx / NSEQ;
+        lds[r * LSEQP + G::nat(f)] = val[u];
+      }
+    } else {
+      for (int idx = tid; idx < T * NSEQ; idx += NT) {
+        const int r = idx % NSEQ, f = idx / NSEQ;
+        lds[r * LSEQP + G::nat(f)] = (bn0 + r < a.NB) ? in[(size_t)f * a.sb + r] : mk2(0.f, 0.f);
+      }
     }
   }
   __syncthreads();
@@ -370,42 +404,52 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   {
     // rows 2s (-> real part) and 2s+1 (-> imaginary part) share one complex inverse FFT:
     // V[f] = Ya[f] + i*Yb[f],  V[T-f] = conj(Ya[f]) + i*conj(Yb[f])
-    // Four bins per thread are requested before any is consumed (the loop is latency-bound otherwise);
-    // a row pair is one 16-byte load when it is whole and aligned.
+    // ALL of a thread's bins are requested before the first is consumed, through a buffer resource over this plane
+    // of bin columns: rows past NY and slots past the last bin get an offset outside it and read as zero.  (Written
+    // with `if (row < NY) load`, hipcc puts every load in its own branch and a full s_waitcnt in front of each
+    // merge: the gather then pays one memory latency per bin.)  A row pair is one 16-byte load when whole and aligned.
     const f2* in = a.src + (((size_t)img * a.NC + c) * a.nxt + xt) * a.Fx * a.NYa + y0;
-    const int total = a.Fx * NSEQ;
-    const bool pair16 = ((a.NYa | y0) & 1) == 0;
-    constexpr int U = 4;
-    for (int base = 0; base < total; base += U * NT) {
-      f2 ya[U], yb2[U];
+    constexpr int FXC = T / 2 + 1;                       // == a.Fx
+    constexpr int TOTAL = FXC * NSEQ;
+    constexpr int NITER = (TOTAL + NT - 1) / NT;
+    // (workgroup-uniform choice, made once: a branch per load would bring the waits back)
+    const int rows_here = a.NY - y0;
+    const bool pair16 = ((a.NYa | y0) & 1) == 0 && !(rows_here < RB && (rows_here & 1));
+    const unsigned plane_bytes = (unsigned)((size_t)(FXC - 1) * a.NYa * 8 + (size_t)min(RB, a.NYa - y0) * 8);
+    const BufRsrc sr = make_rsrc(in, plane_bytes);
+    f2 ya[NITER], yb2[NITER];
+    if (pair16) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = base + u * NT + tid;
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = u * NT + tid;
         const int s = idx % NSEQ, fx = idx / NSEQ;
-        ya[u] = mk2(0.f, 0.f); yb2[u] = mk2(0.f, 0.f);
-        if (idx < total) {
-          const f2* p = in + (size_t)fx * a.NYa + 2 * s;
-          if (pair16 && y0 + 2 * s + 1 < a.NY) {
-            const f4 q = *reinterpret_cast<const f4*>(p);
-            ya[u] = q.xy; yb2[u] = q.zw;
-          } else {
-            if (y0 + 2 * s < a.NY) ya[u] = p[0];
-            if (y0 + 2 * s + 1 < a.NY) yb2[u] = p[1];
-          }
-        }
+        const bool both = idx < TOTAL && y0 + 2 * s + 1 < a.NY;
+        const f4 q = buf_load_f32x4(sr, both ? (unsigned)(((size_t)fx * a.NYa + 2 * s) * 8) : 0xFFFFFFFFu, 0);
+        ya[u] = q.xy; yb2[u] = q.zw;
       }
+    } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = base + u * NT + tid;
-        if (idx < total) {
-          const int s = idx % NSEQ, fx = idx / NSEQ;
-          f2* z = lds + s * LSEQP;
-          if (fx == 0 || fx == T / 2) {
-            z[G::nat(fx)] = mk2(ya[u].x, yb2[u].x);          // both spectra are real at the self-paired bins
-          } else {
-            z[G::nat(fx)] = mk2(ya[u].x - yb2[u].y, ya[u].y + yb2[u].x);
-            z[G::nat(T - fx)] = mk2(ya[u].x + yb2[u].y, yb2[u].x - ya[u].y);
-          }
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = u * NT + tid;
+        const int s = idx % NSEQ, fx = idx / NSEQ;
+        const bool both = idx < TOTAL && y0 + 2 * s + 1 < a.NY;
+        const bool one = idx < TOTAL && y0 + 2 * s < a.NY;
+        const unsigned off = (unsigned)(((size_t)fx * a.NYa + 2 * s) * 8);
+        ya[u] = buf_load_f32x2(sr, one ? off : 0xFFFFFFFFu, 0);
+        yb2[u] = buf_load_f32x2(sr, both ? off + 8u : 0xFFFFFFFFu, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NITER; ++u) {
+      const int idx = u * NT + tid;
+      if (idx < TOTAL) {
+        const int s = idx % NSEQ, fx = idx / NSEQ;
+        f2* z = lds + s * LSEQP;
+        if (fx == 0 || fx == T / 2) {
+          z[G::nat(fx)] = mk2(ya[u].x, yb2[u].x);          // both spectra are real at the self-paired bins
+        } else {
+          z[G::nat(fx)] = mk2(ya[u].x - yb2[u].y, ya[u].y + yb2[u].x);
+          z[G::nat(T - fx)] = mk2(ya[u].x + yb2[u].y, yb2[u].x - ya[u].y);
         }
       }
     }

@@ -46,7 +46,11 @@ __device__ __forceinline__ void stamp_clock(unsigned long long* buf, int item, i
 // pair instead of two channel pairs of one phase, so that a lane can load / store both phases' samples of a position
 // as 8 bytes and trade halves with its partner lane (v_permlane32_swap): half the memory instructions, each
 // touching half the cache lines of the 4-byte accesses at a 4*d-byte pitch.
-template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false, bool PH2 = false>
+// STAMPS: the profiling hook (fc_forward_stamped) is a build of its own -- compiled into the product kernel, even
+// switched off, its guarded stores made hipcc put a full s_waitcnt vmcnt(0) between the two items of a workgroup
+// (a pending store's registers are reused), i.e. a wait for every output store of the first item.
+template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false, bool PH2 = false,
+          bool STAMPS = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   static_assert(!PH2 || (PHASES && !DIAG && !SEG && S == 1 && CIB == 8), "paired phases: plain phase build on a P*P tile");
   using G = Geo<P, S>;
@@ -61,6 +65,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   constexpr int TWN = P * G::N2;            // pass-A twiddle table entries
   extern __shared__ __attribute__((aligned(16))) f2 lds[];
   const Conv1dArgs& a = pa.c;
+  auto stampi = [&](int item, int slot) { if constexpr (STAMPS) stamp_item(a.stamps, item, slot); };
+  auto stampc = [&](int item, int slot) { if constexpr (STAMPS) stamp_clock(a.stamps, item, slot); };
   const int nph = PHASES ? a.ph : 1;          // dilation phases (compile-time 1 in the plain build)
 
   const int tid = threadIdx.x;
@@ -169,22 +175,25 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     // DIAG (depthwise): the spectrum is [channel pair][T/2] float4 = {H(2p)[f], H(2p+1)[f]}, 8 channels per block g
     const BufRsrc wg = DIAG ? make_rsrc(a.wspec + (size_t)g * NPI * (T / 2), (unsigned)(NPI * (T / 2) * 16))
                             : make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
-    stamp_item(a.stamps, it, 0);
-    stamp_clock(a.stamps, it, 12);
+    stampi(it, 0);
+    stampc(it, 12);
     // bias of this lane's two output channels, requested now and used in the last pass
     const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
     const bool ok0 = !DIAG || cg0 < a.Cout, ok1 = !DIAG || cg0 + 1 < a.Cout;
-    const float bias0 = (a.bias && ok0) ? a.bias[cg0] : 0.f;
-    const float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
+    // (buffer loads: a missing bias is an empty resource, a missing channel an offset outside it -- no branch, so
+    // nothing waits for these two values here; they are pinned as arrived after the mix, see below)
+    const BufRsrc brs = make_rsrc(a.bias, a.bias ? (unsigned)a.Cout * 4u : 0u);
+    float bias0 = buf_load_f32(brs, ok0 ? (unsigned)cg0 * 4u : 0xFFFFFFFFu, 0);
+    float bias1 = buf_load_f32(brs, ok1 ? (unsigned)(cg0 + 1) * 4u : 0xFFFFFFFFu, 0);
     // ------------------------------------------------ forward pass A
-    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 1); }
+    if (STAMPS && a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampi(it, 1); }
     // (act_in is wave-uniform and the two passes of a sequence only need wave-level ordering)
     if (act_in) {
       fetch_finish(wi, v);
       passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);
-      stamp_item(a.stamps, it, 2);
+      stampi(it, 2);
       seq_sync<G>();
-      stamp_item(a.stamps, it, 3);
+      stampi(it, 3);
       // ---------------------------------------------- forward pass B
       passB_load<G>(v, zseq, tseq);
       seq_sync<G>();
@@ -206,9 +215,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       const bool sd_act = tid < NB * NPI * 2 && sd_b < wi.nbc;
       f4 sdw = {0.f, 0.f, 0.f, 0.f};
       if (sd_act) sdw = buf_load_f32x4(wg, 0u, sd_p * (T / 2) * 16);
-      stamp_item(a.stamps, it, 4);
+      stampi(it, 4);
       __syncthreads();
-      stamp_item(a.stamps, it, 5);
+      stampi(it, 5);
       static_for<0, BP>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         const int f = tid + m * NT;
@@ -281,9 +290,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       constexpr int s = decltype(sc)::value;
       if constexpr (s < BP * NPI) issue(s / NPI, s % NPI, wr[s]);
     });
-    stamp_item(a.stamps, it, 4);
+    stampi(it, 4);
     __syncthreads();
-    stamp_item(a.stamps, it, 5);
+    stampi(it, 5);
     {
       f2 sbz[NPI];
       if (sb_act) {
@@ -354,9 +363,13 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       }
     }
     }   // dense / depthwise mix
-    stamp_item(a.stamps, it, 6);
+    stampi(it, 6);
     __syncthreads();
-    stamp_item(a.stamps, it, 7);
+    stampi(it, 7);
+    // gfx9 counts loads and stores in ONE vmcnt: a value first used after later memory instructions went out through
+    // branches gets a full s_waitcnt vmcnt(0).  The bias is therefore declared arrived here (only this item's spectrum
+    // loads are older, all consumed), and the next item's samples right before this item's output stores.
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
     // the next item's samples travel from HBM while this item's inverse passes run
     if (more) fetch(wnext, vnext);
     // ------------------------------------------------ inverse pass A'
@@ -364,12 +377,18 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       nat_load<G>(v, zseq, tseq);
       seq_sync<G>();
       passA_fft_twiddle_store_lds<G, +1>(v, zseq, tseq, twl);
-      stamp_item(a.stamps, it, 8);
+      stampi(it, 8);
       seq_sync<G>();
-      stamp_item(a.stamps, it, 9);
+      stampi(it, 9);
       // ---------------------------------------------- inverse pass B' + store
       passB_load<G>(v, zseq, tseq);
       const int j = passB_compute<G, +1>(v, tseq, twB);
+      if (more) {
+        // (requested a whole inverse transform ago: no stall; but behind the stores the next item would have to wait
+        // for every one of them to be acknowledged before it may touch its samples)
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) asm volatile("" : "+v"(vnext[n1]));
+      }
       const int o1 = tseq >> G::LGS;
       const int vb = a.slot_tiles ? wi.b0 : wi.b0 + nb;
       const int tile = a.slot_tiles ? wi.tile + nb : wi.tile;
@@ -469,8 +488,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           if (nbase + P * k < limit) { y0[ystep * k] = v[k].x + bias0; y1[ystep * k] = v[k].y + bias1; }
       }
     }
-    stamp_item(a.stamps, it, 10);
-    if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp_item(a.stamps, it, 11); stamp_clock(a.stamps, it, 13); }
+    stampi(it, 10);
+    if (STAMPS && a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampi(it, 11); stampc(it, 13); }
     seq_sync<G>();     // this wave's sequences are free again (the mix barriers order the other waves)
   };
 
@@ -483,7 +502,16 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     for (int s = 0; s < a.exp_stagger; s += 16) __builtin_amdgcn_s_sleep(16);
   }
   fetch(w0, va);                             // first item's samples and the twiddle table travel together
-  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  {
+    // twiddle table -> LDS: all of a thread's entries requested before the first is stored (a copy loop waits for
+    // every load, one memory latency per iteration, at the start of every workgroup)
+    static_assert(TWN % NT == 0, "whole rounds of the table copy");
+    f2 tw[TWN / NT];
+#pragma unroll
+    for (int i = 0; i < TWN / NT; ++i) tw[i] = a.twA[tid + i * NT];
+#pragma unroll
+    for (int i = 0; i < TWN / NT; ++i) twl[tid + i * NT] = tw[i];
+  }
   __syncthreads();
   run(w0, it0, va, two, w1, vb);
   if (two) run(w1, it1, vb, false, w1, va);

@@ -99,6 +99,13 @@ __device__ __forceinline__ unsigned padded_offset(unsigned row_off, int pos, int
   return ok ? row_off + (unsigned)q * 4u : 0xFFFFFFFFu;
 }
 
+// The same for the zero-spread source of a transposed plan (see load_spread).
+__device__ __forceinline__ unsigned spread_offset(unsigned row_off, int pos, int L, int up, bool chan_ok) {
+  const int q = pos / up;
+  const bool ok = chan_ok && pos >= 0 && q * up == pos && q < L;
+  return ok ? row_off + (unsigned)q * 4u : 0xFFFFFFFFu;
+}
+
 // Profiling hook: lane 0 of each workgroup records the 100 MHz wall clock at phase boundaries.
 __device__ __forceinline__ void stamp(unsigned long long* buf, int slot) {
   if (buf != nullptr && threadIdx.x == 0) buf[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();
@@ -146,11 +153,8 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
       const int ci0 = ic * CIB + 2 * sq;         // channel within the group
       f2 v[P];
       const bool has0 = ci0 < a.Cig, has1 = ci0 + 1 < a.Cig;
-      // rows of phantom channels (ci >= Cig in the last chunk) must not be dereferenced at all: the padded
-      // loaders read row[0] even for a masked lane, and past the last group that is past the tensor
-      const float* rgrp = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig) * a.L;
-      const float* r0 = has0 ? rgrp + (size_t)ci0 * a.L : rgrp;
-      const float* r1 = has1 ? r0 + a.L : rgrp;
+      // (rows of phantom channels -- ci >= Cig in the last chunk, past the tensor for the last group -- are never
+      // dereferenced: every load below goes through the group's buffer resource with an out-of-range offset for them)
       if (interior && has1) {
         const unsigned v0 = ((unsigned)ci0 * (unsigned)a.L + (unsigned)(tile_pos + tseq)) * 4u;
         const unsigned v1 = v0 + (unsigned)a.L * 4u;
@@ -164,13 +168,26 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
         // stages this thread's own column in LDS (no long-lived masks, no register-array indexing),
         // then the column is read back -- same thread, same addresses, so no barrier.  (An unrolled
         // masked-offset variant is used by the batch-sharing kernel; here it made hipcc spill.)
+        // Loads in batches of 8 positions through the group's buffer resource (a masked position or a phantom channel
+        // is an offset outside it: nothing is dereferenced, nothing branches).  One sample per iteration with
+        // `ok ? row[q] : 0` cost one memory latency per sample -- 32 in a row on every tile of a plan with an odd
+        // channel count or a spread source.
         f2* col = zin + sq * G::LSEQ + tseq;
+        const unsigned ro0 = (unsigned)ci0 * (unsigned)a.L * 4u, ro1 = ro0 + (unsigned)a.L * 4u;
+        constexpr int CH = P < 8 ? P : 8;
 #pragma unroll 1
-        for (int n1 = 0; n1 < P; ++n1) {
-          const int pos = tile_pos + G::N2 * n1 + tseq;
-          col[n1 * G::RS] = (a.up == 1)
-                                ? mk2(load_padded(r0, pos, a.L, a.pad, pm, has0), load_padded(r1, pos, a.L, a.pad, pm, has1))
-                                : mk2(load_spread(r0, pos, a.L, a.up, has0), load_spread(r1, pos, a.L, a.up, has1));
+        for (int c0 = 0; c0 < P; c0 += CH) {
+          f2 t[CH];
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            const int pos = tile_pos + G::N2 * (c0 + u) + tseq;
+            const unsigned o0 = (a.up == 1) ? padded_offset(ro0, pos, a.L, a.pad, pm, has0) : spread_offset(ro0, pos, a.L, a.up, has0);
+            const unsigned o1 = (a.up == 1) ? padded_offset(ro1, pos, a.L, a.pad, pm, has1) : spread_offset(ro1, pos, a.L, a.up, has1);
+            t[u].x = buf_load_f32(xg, o0, 0);
+            t[u].y = buf_load_f32(xg, o1, 0);
+          }
+#pragma unroll
+          for (int u = 0; u < CH; ++u) col[(c0 + u) * G::RS] = t[u];
         }
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) v[n1] = col[n1 * G::RS];
@@ -323,8 +340,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_fused_kernel(const Conv1dArgs a)
     const int co0 = oc * a.cob + 2 * sq;           // out channel within the group
     const bool has0 = co0 < a.Cog, has1 = co0 + 1 < a.Cog;
     const int cg0 = g * a.Cog + co0;
-    const float bias0 = (a.bias && has0) ? a.bias[cg0] : 0.f;
-    const float bias1 = (a.bias && has1) ? a.bias[cg0 + 1] : 0.f;
+    // (declared arrived before the guarded stores: met first inside them, hipcc puts a full s_waitcnt vmcnt(0) in front
+    // of every store, and vmcnt counts stores too -- each store then waits for the one before it)
+    float bias0 = (a.bias && has0) ? a.bias[cg0] : 0.f;
+    float bias1 = (a.bias && has1) ? a.bias[cg0 + 1] : 0.f;
+    asm volatile("" : "+v"(bias0), "+v"(bias1));
     const int t0 = tile * a.V;
     const int limit = min(a.V, a.Lfull - t0);      // valid samples of this tile
     const int nbase = o1 + P * P * j;

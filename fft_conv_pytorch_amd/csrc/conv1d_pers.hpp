@@ -502,16 +502,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     for (int s = 0; s < a.exp_stagger; s += 16) __builtin_amdgcn_s_sleep(16);
   }
   fetch(w0, va);                             // first item's samples and the twiddle table travel together
-  {
-    // twiddle table -> LDS: all of a thread's entries requested before the first is stored (a copy loop waits for
-    // every load, one memory latency per iteration, at the start of every workgroup)
-    static_assert(TWN % NT == 0, "whole rounds of the table copy");
-    f2 tw[TWN / NT];
-#pragma unroll
-    for (int i = 0; i < TWN / NT; ++i) tw[i] = a.twA[tid + i * NT];
-#pragma unroll
-    for (int i = 0; i < TWN / NT; ++i) twl[tid + i * NT] = tw[i];
-  }
+  copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
   __syncthreads();
   run(w0, it0, va, two, w1, vb);
   if (two) run(w1, it1, vb, false, w1, va);

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_wide_kernel(const Conv1dPersArgs
   const float bias0 = a.bias ? a.bias[cg0] : 0.f;
   const float bias1 = a.bias ? a.bias[cg0 + 1] : 0.f;
 
-  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
 
   // running sums: [bin pair][batch slot][output pair] x {even, odd output channel}
   f2 ya[BP][NB][NPI], yb[BP][NB][NPI];

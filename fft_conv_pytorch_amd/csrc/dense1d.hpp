@@ -120,8 +120,9 @@ __global__ __launch_bounds__(NT) void dense_inv_kernel(const DenseArgs a) {
   const bool act = co0 < a.Nc;
   const int cg0 = g * a.Cog + co0;
   const bool ok0 = co0 < a.Cog, ok1 = co0 + 1 < a.Cog;
-  const float bias0 = (a.bias && ok0) ? a.bias[cg0] : 0.f;
-  const float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
+  float bias0 = (a.bias && ok0) ? a.bias[cg0] : 0.f;
+  float bias1 = (a.bias && ok1) ? a.bias[cg0 + 1] : 0.f;
+  asm volatile("" : "+v"(bias0), "+v"(bias1));   // (arrived here, not inside the guarded stores: see rows_c2r)
   {
     // gather: lane (s, bin) reads the two channels of pair s at one bin (16 bytes; NSEQ lanes = one run) and
     // re-packs them as Z[f] = Ye + i Yo, Z[T-f] = conj(Ye) + i conj(Yo)

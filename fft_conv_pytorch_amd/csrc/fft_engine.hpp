@@ -253,6 +253,18 @@ __device__ __forceinline__ void lds_arrive(f2 (&v)[N]) {
   for (int i = FIRST; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
+// Twiddle table -> LDS at workgroup start: all of a thread's entries are requested before the first is stored (a
+// copy loop waits for every load: one memory latency per iteration).
+template <int TWN, int NT>
+__device__ __forceinline__ void copy_table_to_lds(f2* __restrict__ twl, const f2* __restrict__ src, int tid) {
+  constexpr int N = (TWN + NT - 1) / NT;
+  f2 tw[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) tw[i] = (TWN % NT == 0 || tid + i * NT < TWN) ? src[tid + i * NT] : mk2(0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < N; ++i) if (TWN % NT == 0 || tid + i * NT < TWN) twl[tid + i * NT] = tw[i];
+}
+
 template <int P_, int S_>
 struct Geo {
   static constexpr int P = P_, S = S_;

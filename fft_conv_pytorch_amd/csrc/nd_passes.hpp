@@ -458,7 +458,10 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   f2 v[P];
   const int j = inv_to_regs_pre<G>(v, wtw, lds + sq * LSEQP, tseq, true, twB);
   const int ya_row = y0 + 2 * sq;
-  const float b = a.bias ? a.bias[img % a.Cout] : 0.f;
+  // (declared arrived before the guarded stores: met first inside them, hipcc puts a full s_waitcnt vmcnt(0) in front of
+  // every store, and vmcnt counts stores too -- each store would wait for the one before it)
+  float b = a.bias ? a.bias[img % a.Cout] : 0.f;
+  asm volatile("" : "+v"(b));
   float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;
   float* o1 = o0 + a.Xo;
   const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const BufRsrc xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.Cin * a.L * 4));
   const BufRsrc yr = make_rsrc(a.dy, (unsigned)((size_t)a.B * a.Cout * a.Lout * 4));
-  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
 
   f2 acc[BP][4][4];                          // [bin pair][o][i]
 #pragma unroll
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_diag_kernel(const WGradArgs a) 
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const BufRsrc xr = make_rsrc(a.x, (unsigned)((size_t)a.B * a.Cin * a.L * 4));
   const BufRsrc yr = make_rsrc(a.dy, (unsigned)((size_t)a.B * a.Cout * a.Lout * 4));
-  for (int i = tid; i < TWN; i += NT) twl[i] = a.twA[i];
+  copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
 
   f2 acc[BP][4][2];                          // [bin pair][channel pair][even / odd channel]
 #pragma unroll

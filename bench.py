@@ -82,6 +82,8 @@ def dominant_kernel_name(plan):
     geo = {64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (32, 1), 2048: (32, 2), 4096: (32, 4)}.get(tile)
     if geo is None:
         return None
+    if wide == 2:
+        return "dense_gemm_kernel<"          # many-channel pipeline: the per-bin GEMM is its longest launch
     if wide:
         return f"conv1d_wide_kernel<{geo[0]}, {geo[1]},"
     if pers_nb:

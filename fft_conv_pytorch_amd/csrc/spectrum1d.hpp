@@ -87,16 +87,30 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
   if (!act) return;
   const float sc = 0.5f / (float)T;
   f4* out = a.wspec + (size_t)seq * (T / 2);
-  for (int f = tseq; f < T / 2; f += G::TS) {
+  // (all bins of this thread read from LDS first, then unpacked and stored: as a loop of read -> unpack -> store every
+  // iteration paid the LDS latency, 16 in a row on the 1024 tile, in a kernel whose whole life is ~8 us)
+  constexpr int NIT = (T / 2) / G::TS;
+  static_assert((T / 2) % G::TS == 0, "whole rounds of bins per thread");
+  f2 zf[NIT], zg[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = tseq + it * G::TS;
+    zf[it] = lds_rd<0>(lds_off(z + G::nat(f)));                       // (asm reads: hipcc would sink them back to their uses)
+    zg[it] = lds_rd<0>(lds_off(z + G::nat((T - f) & (T - 1))));
+  }
+  f2 zh = lds_rd<0>(lds_off(z + G::nat(T / 2)));
+  lds_arrive(zf); lds_arrive(zg);
+  asm volatile("" : "+v"(zh));
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int f = tseq + it * G::TS;
     f4 h;
     if (f == 0) {
-      const f2 z0 = z[G::nat(0)], zh = z[G::nat(T / 2)];
-      h.x = z0.x * sc; h.y = zh.x * sc; h.z = z0.y * sc; h.w = zh.y * sc;
+      h.x = zf[it].x * sc; h.y = zh.x * sc; h.z = zf[it].y * sc; h.w = zh.y * sc;
     } else {
-      const f2 zf = z[G::nat(f)], zg = z[G::nat(T - f)];
       // W_a = (Zf + conj(Zg))/2, W_b = (Zf - conj(Zg))/(2i); H = conj(W)/(2T)
       const float h2 = 0.5f * sc;
-      h.x = (zf.x + zg.x) * h2; h.y = -(zf.y - zg.y) * h2; h.z = (zf.y + zg.y) * h2; h.w = -(zg.x - zf.x) * h2;
+      h.x = (zf[it].x + zg[it].x) * h2; h.y = -(zf[it].y - zg[it].y) * h2; h.z = (zf[it].y + zg[it].y) * h2; h.w = -(zg[it].x - zf[it].x) * h2;
     }
     out[f] = h;
   }

@@ -91,11 +91,23 @@ __global__ __launch_bounds__(NT) void dense_fwd_kernel(const DenseArgs a) {
   const f2* z = lds + s * LSEQP;
   f4* out = reinterpret_cast<f4*>(a.X + (((size_t)g * NF) * a.mcount + ml) * a.Kc + 2 * (cb * NSEQ + s));
   const size_t fstride = (size_t)a.mcount * a.Kc / 2;      // f4 units between bins
-  for (int f = fsub; f < NF; f += NFS) {
-    const f2 zf = z[G::nat(f)], zg = z[G::nat((T - f) & (T - 1))];
-    const f2 xe = add_conj(zf, zg), xo = sub_conj_divi(zf, zg);
+  // (all of a lane's bins read from LDS first -- asm reads, hipcc would sink them back to their uses -- then unpacked
+  // and stored: one LDS latency instead of one per bin)
+  constexpr int NITER = (NF + NFS - 1) / NFS;
+  f2 zf[NITER], zg[NITER];
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int f = min(fsub + NFS * it, NF - 1);            // (the last round is partly idle: clamped, not stored)
+    zf[it] = lds_rd<0>(lds_off(z + G::nat(f)));
+    zg[it] = lds_rd<0>(lds_off(z + G::nat((T - f) & (T - 1))));
+  }
+  lds_arrive(zf); lds_arrive(zg);
+#pragma unroll
+  for (int it = 0; it < NITER; ++it) {
+    const int f = fsub + NFS * it;
+    const f2 xe = add_conj(zf[it], zg[it]), xo = sub_conj_divi(zf[it], zg[it]);
     f4 o; o.x = xe.x; o.y = xe.y; o.z = xo.x; o.w = xo.y;
-    if (st_ok) out[(size_t)f * fstride] = o;
+    if (st_ok && f < NF) out[(size_t)f * fstride] = o;
   }
 }
 

@@ -1079,7 +1079,10 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = p.padl[ax]; m.mode = p.d.padding_mode; m.up = p.up[ax]; return m; };
   fc::RowsR2CArgs r{};
   r.src = x; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 0;
-  r.mx = amap(nd - 1); r.my = amap(nd - 2); r.mz = amap(0);
+  r.mx = amap(nd - 1); r.my = amap(nd - 2);
+  // a one-plane padded z axis still goes through its map: a transposed plan can crop its only source plane away
+  if (nd == 3) r.mz = amap(0);
+  else { r.mz.size = 1; r.mz.pad = 0; r.mz.mode = FC_PAD_CONSTANT; r.mz.up = 1; }
   r.kx = r.ky = r.kz = r.dx = r.dy = r.dz = 1; r.transposed = 0; r.Cig = p.Cig; r.Cog = p.Cog;
   r.NA = B * Ci; r.NC = nd == 3 ? p.Sp[0] : 1; r.NY = p.Sp[nd - 2]; r.NYa = r.NY;
   r.SZ = nd == 3 ? (int)p.d.spatial[0] : 1; r.SY = (int)p.d.spatial[nd - 2]; r.SX = (int)p.d.spatial[nd - 1]; r.Fx = p.Fx;

@@ -119,7 +119,7 @@ struct RowsR2CArgs {
   int from_kernel;       // 0: signal with padding maps, 1: dilated kernel taps
   int transposed;        // kernel taps of a transposed plan: (Cin, Cout/g, *k), flipped, in/out swapped per group
   int Cig, Cog;          // (kernel source only)
-  AxisMap mx, my, mz;    // signal: per-axis padding maps (mz unused for 2-D)
+  AxisMap mx, my, mz;    // signal: per-axis padding maps (mz: the identity {1, 0, constant, 1} for 2-D)
   int kx, ky, kz, dx, dy, dz;   // kernel: taps and dilation per axis
   int NA, NC, NY, NYa;   // images, planes per image (padded), rows per plane (padded), row stride of dst
   int SZ, SY, SX;        // source extents (signal: unpadded sizes; kernel: taps)
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
         zs = tap_src(c, a.dz, a.kz);
       } else {
         ys = yp < a.NY ? axis_src(a.my, yp) : -1;
-        zs = a.NC > 1 ? axis_src(a.mz, c) : 0;
+        zs = axis_src(a.mz, c);       // (2-D plans carry an identity map here)
       }
       ok[h] = ys >= 0 && zs >= 0;
       size_t simg = img;

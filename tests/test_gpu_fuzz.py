@@ -121,3 +121,29 @@ def test_transposed_fuzz(ndim, count):
         assert err < REL_TOL, (kw, size, err)
         worst = max(worst, err)
     print(f"transposed fuzz {ndim}-D: worst rel err {worst:.2e}")
+
+
+@pytest.mark.parametrize("size,k,stride,pad", [
+    ([1, 18, 10], 1, 2, 1),     # found by scripts/fuzz_extended.py seed 22: the only z plane of dX is cropped away
+    ([1, 7, 9], 1, 3, 1),
+    ([2, 6, 5], 1, 2, 1),
+    ([1, 1, 12], 1, 2, 1),
+])
+def test_input_gradient_when_an_axis_only_meets_padding(size, k, stride, pad):
+    """Strided 3-D convolution whose taps along a one-sample axis only ever land on the zero padding: the forward
+    output is the bias and dX is exactly zero there.  The dX plan (transposed, left crop -1) has a padded z extent
+    of one plane, which used to skip the z-axis source map and read the plane it should have cropped."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(2222)
+    x = torch.randn(3, 3, *size, generator=gen, dtype=torch.float64)
+    w = torch.randn(8, 3, k, k, k, generator=gen, dtype=torch.float64)
+    b = torch.randn(8, generator=gen, dtype=torch.float64)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    want = F.conv3d(xr, wr, br, stride=stride, padding=pad)
+    xd, wd, bd = (t.float().to(DEV).requires_grad_(True) for t in (x, w, b))
+    got = fft_conv(xd, wd, bias=bd, stride=stride, padding=pad)
+    gy = torch.randn(want.shape, generator=gen, dtype=torch.float64)
+    want.backward(gy)
+    got.backward(gy.float().to(DEV))
+    errs = [_rel(got.detach(), want.detach()), _rel(xd.grad, xr.grad), _rel(wd.grad, wr.grad), _rel(bd.grad, br.grad)]
+    assert max(errs) < REL_TOL, errs

@@ -146,7 +146,7 @@ struct fc_plan {
   Twiddles twx, twm;
   int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
   int padl[3], up[3], ostride[3];   // left pad in grid coordinates, source spread step, output decimation
-  int Fx;                     // Tx/2 + 1
+  int Fx;                     // Tx/2
   int nxt, Vx, Fxt;           // overlap-save tiles along the rows axis (nxt = 1: one full-length transform), valid
                               // stride-1 samples per tile, bin columns per plane = nxt * Fx
   int nyt, Vy;                // the same for the middle axis of a 3-D problem (one c2c launch per tile)
@@ -586,7 +586,7 @@ static int plan_nd(fc_plan* p) {
       p->nxt = (int)((p->Lf[nd - 1] + p->Vx - 1) / p->Vx);
     }
   }
-  p->Fx = p->tx->T / 2 + 1;
+  p->Fx = p->tx->T / 2;        // odd-frequency bins along the rows axis (nd_passes.hpp, rows_r2c)
   p->Fxt = p->nxt * p->Fx;
   p->tm = nullptr;
   p->nyt = 1;

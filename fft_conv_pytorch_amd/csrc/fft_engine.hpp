@@ -104,6 +104,20 @@ __host__ __device__ constexpr float cos128(int q) {
 }
 __host__ __device__ constexpr float sin128(int q) { return cos128(q - 32); }
 
+// cos(pi*num/den), sin(pi*num/den) at compile time (argument folded into [0, pi/2], 12 Taylor terms in double)
+__host__ __device__ constexpr double cospi_q(long long num, long long den) {
+  num %= 2 * den;
+  if (num < 0) num += 2 * den;
+  if (num > den) num = 2 * den - num;
+  bool neg = false;
+  if (2 * num > den) { num = den - num; neg = true; }
+  const double a = 3.14159265358979323846 * (double)num / (double)den;
+  double term = 1.0, sum = 1.0;
+  for (int k = 1; k <= 12; ++k) { term *= -a * a / ((2.0 * k - 1.0) * (2.0 * k)); sum += term; }
+  return neg ? -sum : sum;
+}
+__host__ __device__ constexpr double sinpi_q(long long num, long long den) { return cospi_q(2 * num - den, 2 * den); }
+
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 __host__ __device__ constexpr int bitrev(int v, int bits) {
   int r = 0;

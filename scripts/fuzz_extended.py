@@ -44,6 +44,8 @@ for ndim, count in counts.items():
         if max(errs) >= 1e-4:
             print("MISMATCH", errs, flush=True)
             sys.exit(1)
+        if max(errs) > 3e-6:
+            print("  errs (y, dX, dW, db):", ["%.1e" % e for e in errs], flush=True)
         worst = max(worst, max(errs))
 print(f"extended fuzz seed {seed}: worst rel err {worst:.2e}")
 

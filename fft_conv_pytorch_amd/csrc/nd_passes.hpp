@@ -220,16 +220,31 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   fwd_from_regs<G>(v, lds + sq * LSEQP, tseq, true, twA, twB);
   __syncthreads();
   // unpack the two real spectra of every pair (partner of bin k: T-1-k) and store transposed: RB rows contiguous per bin
+  // (a thread keeps its row r = tid % RB over all rounds and steps NT/RB bins per round: every LDS read of the thread is
+  // requested before the first value is used, and the stores are buffer stores relative to this workgroup's block of bin
+  // columns -- 32-bit offsets, rows past NY get an out-of-range offset instead of a branch)
+  constexpr int FXC = T / 2;                       // == a.Fx
+  static_assert(NT % RB == 0 && (FXC * RB) % NT == 0, "whole rounds, fixed row per thread");
+  constexpr int NROUND = FXC * RB / NT, FSTEP = NT / RB;
   f2* out = a.dst + (((size_t)img * a.NC + c) * a.nxt + xt) * a.Fx * a.NYa + y0;
-  for (int idx = tid; idx < a.Fx * RB; idx += NT) {
-    const int r = idx % RB, fx = idx / RB;
-    if (y0 + r >= a.NY) continue;
-    const f2* z = lds + (r >> 1) * LSEQP;
-    const f2 zf = z[G::nat(fx)], zg = z[G::nat(T - 1 - fx)];
-    f2 xv;
-    if ((r & 1) == 0) xv = mk2(0.5f * (zf.x + zg.x), 0.5f * (zf.y - zg.y));
-    else xv = mk2(0.5f * (zf.y + zg.y), 0.5f * (zg.x - zf.x));
-    out[(size_t)fx * a.NYa + r] = xv;
+  const BufRsrc orr = make_rsrc(out, (unsigned)(((size_t)(FXC - 1) * a.NYa + min(RB, a.NYa - y0)) * 8));
+  const int r = tid % RB, fx0 = tid / RB;
+  const f2* z = lds + (r >> 1) * LSEQP;
+  f2 zf[NROUND], zg[NROUND];
+#pragma unroll
+  for (int u = 0; u < NROUND; ++u) {
+    const int fx = fx0 + u * FSTEP;
+    zf[u] = z[G::nat(fx)];
+    zg[u] = z[G::nat(T - 1 - fx)];
+  }
+  const bool odd = (r & 1) != 0;
+  const unsigned rofs = (unsigned)r * 8u, rbad = (y0 + r < a.NY) ? 0u : 0x80000000u;
+#pragma unroll
+  for (int u = 0; u < NROUND; ++u) {
+    const int fx = fx0 + u * FSTEP;
+    const f2 ev = mk2(0.5f * (zf[u].x + zg[u].x), 0.5f * (zf[u].y - zg[u].y));
+    const f2 ov = mk2(0.5f * (zf[u].y + zg[u].y), 0.5f * (zg[u].x - zf[u].x));
+    buf_store_f32x2(odd ? ov : ev, orr, (rofs + (unsigned)(fx * a.NYa) * 8u) | rbad, 0);
   }
 }
 
@@ -485,20 +500,22 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   // every store, and vmcnt counts stores too -- each store would wait for the one before it)
   float b = a.bias ? a.bias[img % a.Cout] : 0.f;
   asm volatile("" : "+v"(b));
-  float* o0 = a.dst + (((size_t)img * a.NC + c) * a.NY + ya_row) * a.Xo;
-  float* o1 = o0 + a.Xo;
+  // buffer stores relative to this workgroup's RB output rows (32-bit offsets; samples past the valid window, decimated
+  // away or in rows past NY get an out-of-range offset instead of a branch)
+  float* orow = a.dst + (((size_t)img * a.NC + c) * a.NY + y0) * a.Xo;
+  const BufRsrc orr = make_rsrc(orow, (unsigned)((size_t)min(RB, a.NY - y0) * a.Xo * 4));
   const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;
+  // (offsets are sums of small row and column parts; bit 31 marks a store that must not happen)
+  const unsigned r0 = (unsigned)(2 * sq * a.Xo) * 4u, r1 = r0 + (unsigned)a.Xo * 4u;
+  const unsigned bad0 = has0 ? 0u : 0x80000000u, bad1 = has1 ? 0u : 0x80000000u;
   const int nbase = (tseq >> G::LGS) + P * P * j;
   if (a.stride == 1) {
-    o0 += x0; o1 += x0;
-    if (has1) {
 #pragma unroll
-      for (int k = 0; k < P; ++k)
-        if (nbase + P * k < xlim) { o0[nbase + P * k] = v[k].x + b; o1[nbase + P * k] = v[k].y + b; }
-    } else if (has0) {
-#pragma unroll
-      for (int k = 0; k < P; ++k)
-        if (nbase + P * k < xlim) o0[nbase + P * k] = v[k].x + b;
+    for (int k = 0; k < P; ++k) {
+      const int n = nbase + P * k;
+      const unsigned xo = (unsigned)(x0 + n) * 4u, badx = n < xlim ? 0u : 0x80000000u;
+      buf_store_f32(v[k].x + b, orr, (r0 + xo) | bad0 | badx, 0);
+      buf_store_f32(v[k].y + b, orr, (r1 + xo) | bad1 | badx, 0);
     }
     return;
   }
@@ -507,10 +524,9 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
     const int n = nbase + P * k;
     const int t = x0 + n;
     const int idx = t / a.stride;
-    if (n < xlim && idx * a.stride == t) {
-      if (has0) o0[idx] = v[k].x + b;
-      if (has1) o1[idx] = v[k].y + b;
-    }
+    const unsigned xo = (unsigned)idx * 4u, badx = (n < xlim && idx * a.stride == t) ? 0u : 0x80000000u;
+    buf_store_f32(v[k].x + b, orr, (r0 + xo) | bad0 | badx, 0);
+    buf_store_f32(v[k].y + b, orr, (r1 + xo) | bad1 | badx, 0);
   }
 }
 

@@ -101,3 +101,42 @@ def test_oracle_autograd_matches_reference_gradients_g5():
         gu.check_entry(bt.grad.numpy(), gold["db"], TIGHT)
         count[kind] += 1
     assert count["fwd"] >= 15 and count["tr"] >= 12
+
+
+def test_odd_frequency_real_axis_gives_same_valid_outputs():
+    """The scheme of the HIP row passes (csrc/nd_passes.hpp, rows_r2c / rows_c2r), restated in numpy: samples turned by
+    e^{-i*pi*n/T} before a complex FFT (bin k at frequency k + 1/2), two real rows per transform unpacked with the partner
+    bin T-1-k, T/2 bins kept per row, the product with the conjugated kernel bins, the mirrored pack, the inverse FFT and the
+    turn back.  The result is the negacyclic correlation: identical to the reference's rfft/irfft formulation
+    (/root/reference/fft_conv_pytorch/functional.py:66-82) on the valid window, which is all that overlap-save keeps."""
+    rng = np.random.default_rng(7)
+    T, K = 64, 9
+    n = np.arange(T)
+    turn = np.exp(-1j * np.pi * n / T)
+    rows = rng.standard_normal((2, T))
+    taps = np.zeros(T)
+    taps[:K] = rng.standard_normal(K)
+
+    def half_bins_of_two_rows(a, b):
+        z = np.fft.fft((a + 1j * b) * turn)
+        zp = np.conj(z[T - 1 - np.arange(T // 2)])            # partner of bin k: T-1-k
+        zk = z[: T // 2]
+        return 0.5 * (zk + zp), -0.5j * (zk - zp)             # odd-frequency bins k < T/2 of row a and of row b
+
+    xa, xb = half_bins_of_two_rows(rows[0], rows[1])
+    ha, _ = half_bins_of_two_rows(taps, np.zeros(T))
+    # each row's own spectrum really is the odd-frequency DFT of that row
+    direct = np.array([np.sum(rows[0] * np.exp(-2j * np.pi * n * (k + 0.5) / T)) for k in range(T // 2)])
+    assert np.allclose(xa, direct, atol=1e-10)
+    ya, yb = xa * np.conj(ha), xb * np.conj(ha)               # correlation, as the reference's conj(kernel_fr)
+    v = np.zeros(T, dtype=complex)
+    v[: T // 2] = ya + 1j * yb
+    v[T - 1 - np.arange(T // 2)] = np.conj(ya) + 1j * np.conj(yb)
+    out = np.fft.ifft(v) * np.conj(turn)
+    want = np.stack([np.correlate(r, taps[:K], mode="valid") for r in rows])        # T - K + 1 valid samples
+    assert np.allclose(out.real[: T - K + 1], want[0], atol=1e-10)
+    assert np.allclose(out.imag[: T - K + 1], want[1], atol=1e-10)
+    # ... and the wrapped samples are the negated wrap-around (negacyclic), not the cyclic one: never kept
+    cyc = np.fft.irfft(np.fft.rfft(rows[0]) * np.conj(np.fft.rfft(taps)), T)
+    assert np.allclose(cyc[: T - K + 1], want[0], atol=1e-10)
+    assert not np.allclose(cyc[T - K + 1:], out.real[T - K + 1:], atol=1e-6)

@@ -698,10 +698,27 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   const int j = inv_to_regs<G>(v, vout + sq * LSEQP, tseq, act, twA, twB);
   stampc(6);
   const int co = oc * a.cob + ch;
-  if (act && co < a.Cog) {
+  const bool live = act && co < a.Cog;
+  const int limit = min(a.V, a.Lfull - t0);
+  const int nbase = (tseq >> G::LGS) + P * P * j;
+  // rows of this workgroup: batch items b0 .. b0+nbc-1, all output channels of the group, this column
+  f2* out0 = a.dst + (((size_t)b0 * a.Cout + (size_t)g * a.Cog) * a.ncol + col) * a.NVo;
+  const long long ospan = ((long long)(nbc - 1) * a.Cout + a.Cog - 1) * a.ncol * a.NVo + a.NVo;
+  if (ospan * 8 < 0x7fffffffLL) {
+    // buffer stores relative to the workgroup's first row (idle sequences, samples past the valid window or decimated
+    // away: bit 31 of the offset instead of a branch)
+    const BufRsrc orr = make_rsrc(out0, (unsigned)(ospan * 8));
+    const unsigned ro = live ? (unsigned)((((long long)nbi * a.Cout + co) * a.ncol * a.NVo) * 8) : 0u;
+    const unsigned rbad = live ? 0u : 0x80000000u;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+      const int n = nbase + P * k;
+      const int t = t0 + n;
+      const int idx = t / a.stride;
+      buf_store_f32x2(v[k], orr, (ro + (unsigned)idx * 8u) | rbad | ((n < limit && idx * a.stride == t) ? 0u : 0x80000000u), 0);
+    }
+  } else if (live) {
     f2* out = a.dst + (((size_t)(b0 + nbi) * a.Cout + (size_t)g * a.Cog + co) * a.ncol + col) * a.NVo;
-    const int limit = min(a.V, a.Lfull - t0);
-    const int nbase = (tseq >> G::LGS) + P * P * j;
 #pragma unroll
     for (int k = 0; k < P; ++k) {
       const int n = nbase + P * k;

@@ -588,6 +588,13 @@ static int plan_nd(fc_plan* p) {
   }
   p->Fx = p->tx->T / 2;        // odd-frequency bins along the rows axis (nd_passes.hpp, rows_r2c)
   p->Fxt = p->nxt * p->Fx;
+  {
+    // the row passes address one (bin column, row) block per workgroup with 32-bit byte offsets
+    const int64_t rows = std::max<int64_t>(p->Sp[nd - 2], p->out_sp[nd - 2]);
+    if ((int64_t)p->Fx * rows * 8 >= ((int64_t)1 << 31))
+      return fail(FC_ERR_UNSUPPORTED, "%lld rows of %d-point transforms along the last axis exceed the 2 GiB a block of bin "
+                  "columns may span (split the second-to-last axis)", (long long)rows, p->tx->T);
+  }
   p->tm = nullptr;
   p->nyt = 1;
   p->Vy = nd == 3 ? p->Lf[1] : 0;

@@ -289,6 +289,22 @@ def test_tensor_on_a_non_current_device():
         fft_conv(x, w.to("cuda:0"))
 
 
+def test_nd_block_of_bin_columns_beyond_2_gib_is_refused():
+    """The row passes address one block of bin columns per workgroup with 32-bit byte offsets: a second-to-last axis so long
+    that Tx/2 bin columns of it span 2 GiB is refused at plan creation (a documented limit) instead of
+    computing with wrapped offsets.  Just below the limit the same shape family still runs."""
+    from fft_conv_pytorch_amd.functional import fft_conv
+    w = torch.randn(1, 1, 3, 3, device=DEV)
+    x = torch.empty(1, 1, 540000, 600, device=DEV)             # padded row 600 -> 1024-point transforms, 512 bin columns
+    with pytest.raises(NotImplementedError, match="2 GiB"):
+        fft_conv(x, w)
+    del x
+    x = torch.randn(1, 1, 300000, 40, device=DEV)              # 64-point transforms: 32 columns x 300000 rows = 77 MB
+    y = fft_conv(x, w)
+    want = F.conv2d(x.double().cpu(), w.double().cpu())
+    assert _rel(y, want) < REL_TOL
+
+
 # ----------------------------------------------------------------------------- rows longer than the largest FFT (N-d)
 def test_nd_rows_longer_than_4096():
     """The reference has no size limit (functional.py:66-70).  The last axis of a 2-D / 3-D problem runs in

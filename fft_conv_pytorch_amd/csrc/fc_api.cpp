@@ -594,6 +594,10 @@ static int plan_nd(fc_plan* p) {
     if ((int64_t)p->Fx * rows * 8 >= ((int64_t)1 << 31))
       return fail(FC_ERR_UNSUPPORTED, "%lld rows of %d-point transforms along the last axis exceed the 2 GiB a block of bin "
                   "columns may span (split the second-to-last axis)", (long long)rows, p->tx->T);
+    // ... and the rows_c2r output stores a workgroup's (at most 32) output rows the same way
+    if (p->out_sp[nd - 1] * 4 * 32 >= ((int64_t)1 << 31))
+      return fail(FC_ERR_UNSUPPORTED, "output rows of %lld samples exceed the 2 GiB a workgroup's block of rows may span "
+                  "(2-D / 3-D plans; 1-D rows have no such limit)", (long long)p->out_sp[nd - 1]);
   }
   p->tm = nullptr;
   p->nyt = 1;

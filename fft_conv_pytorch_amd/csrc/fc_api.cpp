@@ -151,6 +151,7 @@ struct fc_plan {
                               // stride-1 samples per tile, bin columns per plane = nxt * Fx
   int nyt, Vy;                // the same for the middle axis of a 3-D problem (one c2c launch per tile)
   int nd_cob, nd_Cog_pad;
+  int planes;                 // 3-D: plane-major three-launch pipeline (planes3d.hpp) instead of the five separable passes
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
@@ -620,6 +621,17 @@ static int plan_nd(fc_plan* p) {
   // channel blocking of the fused (complex) pass: one sequence per channel
   p->nd_cob = std::min(p->CB, p->Cog);
   p->nd_Cog_pad = (int)round_up(p->Cog, p->nd_cob);
+  // Plane-major 3-D pipeline (planes3d.hpp): padded (y, x) planes within one 64 x 64 transform, 8-channel chunks with a
+  // single input chunk, and a 64-point z tile (taken whenever the z kernel leaves at least half of it valid).
+  // FFTCONV_PLANES=0 keeps the separable passes (A/B runs, tests).
+  bool planes_ok = false;
+  {
+    const char* env = getenv("FFTCONV_PLANES");
+    const fc::TileImpl* t64 = find_tile(64);
+    planes_ok = (!env || atoi(env) != 0) && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 && p->nxt == 1 &&
+                p->nyt == 1 && p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) &&
+                (int64_t)2 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) < 65536;   // (32-bit offsets below 2 GiB per workgroup)
+  }
   // overlap-save tiles along the outermost axis
   const int64_t Kd = p->kd[0], Lfull = p->Lf[0];
   const size_t lds_cap = 160 * 1024;
@@ -630,6 +642,7 @@ static int plan_nd(fc_plan* p) {
   for (int i = 0; i < ntl; ++i) {
     const fc::TileImpl* t = tiles[i];
     if (d.tile_hint && t->T != d.tile_hint) continue;
+    if (planes_ok && t->T != 64) continue;
     if (t->T < Kd || p->CB > t->fusedc_max_cib) continue;
     const size_t lds = (size_t)(p->accumulate ? 2 : 1) * p->CB * t->lseqp * sizeof(fc::f2);
     if (lds > lds_cap) continue;
@@ -669,6 +682,11 @@ static int plan_nd(fc_plan* p) {
                      B * Co * (size_t)p->out_sp[0] * Fs * (size_t)p->out_sp[1]);   // O1[(b,co)][z_out][xt,fx][y_out]
     a_w = Co * p->Cig * (size_t)p->kd[0] * Fx * (size_t)p->kd[1];
     b_w = Co * p->Cig * Fx * Ty * (size_t)p->kd[0];
+  }
+  p->planes = planes_ok && best->T == 64;
+  if (p->planes) {
+    a_sig = B * Ci * (size_t)p->Sp[0] * fc::kPlCols;              // S[(b,ci)][zp][col]
+    b_sig = B * Co * (size_t)p->out_sp[0] * fc::kPlCols;          // O[(b,co)][z_out][col]
   }
   p->ws_a = std::max(a_sig, a_w);
   p->ws_b = std::max(b_sig, b_w);
@@ -885,6 +903,8 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->d.dtype != FC_F32) return 0;
+  if (plan->nd == 3 && plan->planes)   // upper bound of colz's grid (one batch item per workgroup)
+    return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * (fc::kPlCols / 16);
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
     const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T * plan->nyt;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
@@ -1088,6 +1108,29 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   const int nd = p.nd;
   const int B = (int)p.d.batch, Ci = (int)p.d.in_channels, Co = (int)p.d.out_channels;
   auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = p.padl[ax]; m.mode = p.d.padding_mode; m.up = p.up[ax]; return m; };
+  if (p.planes) {
+    // x (B,Ci,Z,Y,X) -> S[(b,ci)][zp][col] -> O[(b,co)][z_out][col] -> y; col = fx*64 + fy
+    fc::PlaneFwdArgs f1{};
+    f1.src = x; f1.dst = wsA; f1.twA = p.twx.twA; f1.twB = p.twx.twB;
+    f1.mx = amap(2); f1.my = amap(1); f1.mz = amap(0);
+    f1.SZ = (int)p.d.spatial[0]; f1.SY = (int)p.d.spatial[1]; f1.SX = (int)p.d.spatial[2]; f1.NZ = p.Sp[0];
+    FC_HIP(p.tile->planes_fwd(f1, B * Ci, st));
+    fc::ColZArgs cz{};
+    cz.src = wsA; cz.wspec = (const fc::f4*)w_hat; cz.dst = wsB;
+    cz.B = B; cz.Cin = Ci; cz.Cout = Co; cz.G = (int)p.d.groups; cz.Cig = p.Cig; cz.Cog = p.Cog; cz.Cog_pad = p.nd_Cog_pad;
+    cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
+    cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
+    cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
+    cz.stamps = (unsigned long long*)stamps;        // profiling build of the column pass (scripts/phase_profile_nd.py)
+    FC_HIP(p.tile->colz(cz, st));
+    fc::PlaneInvArgs f3{};
+    f3.src = wsB; f3.dst = y; f3.bias = p.d.has_bias ? bias : nullptr; f3.twA = p.twx.twA; f3.twB = p.twx.twB;
+    f3.NZo = (int)p.out_sp[0]; f3.Cout = Co;
+    f3.NVy = p.Lf[1]; f3.sy = p.ostride[1]; f3.Yo = (int)p.out_sp[1];
+    f3.NVx = p.Lf[2]; f3.sx = p.ostride[2]; f3.Xo = (int)p.out_sp[2];
+    FC_HIP(p.tile->planes_inv(f3, B * Co, st));
+    return FC_OK;
+  }
   fc::RowsR2CArgs r{};
   r.src = x; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 0;
   r.mx = amap(nd - 1); r.my = amap(nd - 2);

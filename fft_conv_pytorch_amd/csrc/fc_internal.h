@@ -8,6 +8,7 @@
 #include "dense1d.hpp"
 #include "spectrum1d.hpp"
 #include "wgrad1d.hpp"
+#include "planes3d.hpp"
 
 namespace fc {
 
@@ -42,6 +43,10 @@ struct TileImpl {
   // transforms, 1 per-bin GEMM (MFMA), 2 inverse transforms
   hipError_t (*dense)(int which, const DenseArgs& a, hipStream_t st);
   hipError_t (*dense_spec)(const DenseSpecArgs& a, hipStream_t st);
+  // plane-major 3-D pipeline (planes3d.hpp), built for the 64-point tile only (else null)
+  hipError_t (*planes_fwd)(const PlaneFwdArgs& a, int n_images, hipStream_t st);
+  hipError_t (*colz)(const ColZArgs& a, hipStream_t st);
+  hipError_t (*planes_inv)(const PlaneInvArgs& a, int n_images, hipStream_t st);
 };
 
 #define FC_DECLARE_TILE(P, S) const TileImpl* get_tile_P##P##_S##S();

@@ -1,0 +1,459 @@
+// planes3d.hpp -- plane-major 3-D pipeline: three launches instead of five.
+//
+// The reference transforms all three axes in one rfftn / irfftn (functional.py:66-75).  The separable scheme of
+// nd_passes.hpp runs one launch per axis and side (rows_r2c, c2c_fwd, fusedc, c2c_inv, rows_c2r): 5.1x the algorithmic
+// HBM bytes at cfgC.  When the padded (y, x) plane fits a 64 x 64 transform and the z tile is 64 points, a whole
+// plane's half-spectrum (32 x 64 complex = 16 KB) fits one workgroup's LDS, so both plane axes are fused on each side
+// of the z pass and every intermediate is kept PLANE-MAJOR -- [(b, c)][z][col], col = fx*64 + fy, 2048 bin columns:
+//
+//   planes_fwd  one (b, ci, z) plane per workgroup: 16 KB in (contiguous), x rows (two real rows per complex FFT,
+//               odd-frequency bins, see rows_r2c) -> unpack through DPP -> y columns -> 16 KB out (contiguous)
+//   colz        one block of 16 neighbouring columns x NB batch items per workgroup.  ONE THREAD OWNS ONE SEQUENCE:
+//               lane = column, so the 64 z samples of a thread are 64 loads of which every wave-instruction reads
+//               4 x 128 contiguous bytes of a plane -- no transposition anywhere -- and the 64-point transforms run
+//               entirely in registers (no LDS exchange).  Only the channel contraction crosses threads: the bins
+//               travel through LDS in chunks of FC frequencies (threads swap roles: bin owner <-> sequence owner),
+//               NB batch items share every kernel-spectrum load.  Stores mirror the loads.
+//   planes_inv  one (b, co, z_out) plane per workgroup: y columns back, x rows back (c2r, valid window, stride, bias),
+//               output plane staged in LDS and written as one contiguous run.
+//
+// HBM bytes at cfgC: x 67 + S 2x67 + H 67 + O 2x59 + y 45 = 430 MB (separable: 577 MB), three launches.
+// The kernel transform keeps the separable passes (it runs once per weight version and produces the same
+// [g][o][i/2][col][fz] layout).
+#pragma once
+#include "nd_passes.hpp"
+
+namespace fc {
+
+constexpr int kPlFx = 32;                 // odd-frequency bins along x
+constexpr int kPlCols = kPlFx * 64;       // bin columns per plane
+constexpr int kPlNT = 256;
+constexpr int kPlPitch = 72;              // complex slots per LDS sequence: the engine's 8 rows of 9, and conflict-free for
+                                          // 8 lanes x 4 sequences reading the same element index
+
+__device__ __forceinline__ float dpp_half_mirror(float v) {   // lane i <- lane 7 - i inside every group of 8 lanes
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+
+// ------------------------------------------------------------------------------------------ planes_fwd
+struct PlaneFwdArgs {
+  const float* src;      // signal (B, C, Z, Y, X)
+  f2* dst;               // S [(b*C + ci)][NZ][2048]
+  const f2* twA;         // tables of the 64-point tile
+  const f2* twB;
+  AxisMap mx, my, mz;    // padding maps (functional.py:60-62 folded into the loads)
+  int SZ, SY, SX;        // source extents
+  int NZ;                // padded planes per image
+};
+
+template <int NT_>
+__global__ __launch_bounds__(kPlNT) void planes_fwd_kernel(const PlaneFwdArgs a) {
+  using G = Geo<8, 1>;
+  // ONE 18 KB region serves, one after the other, as row buffer, x-pass exchange, [fx][y] transpose, y-pass exchange and
+  // output staging (a workgroup barrier at every change of hands): eight workgroups per CU instead of four
+  __shared__ __attribute__((aligned(16))) f2 reg[32 * kPlPitch];
+  float* rowbuf = reinterpret_cast<float*>(reg);          // [64][68] floats while the plane is loaded
+  constexpr int RP = 68;
+  static_assert(64 * RP * 4 <= 32 * kPlPitch * 8, "row buffer fits the region");
+  const BufRsrc twA = make_rsrc(a.twA, 8 * 8 * 8), twB = make_rsrc(a.twB, 8 * 8);
+  const int tid = threadIdx.x, sq = tid >> 3, tseq = tid & 7;
+  const int img = blockIdx.x / a.NZ, zp = blockIdx.x - img * a.NZ;
+  f4* outp = reinterpret_cast<f4*>(a.dst + ((size_t)img * a.NZ + zp) * kPlCols);
+  const int zs = axis_src(a.mz, zp);
+  if (zs < 0) {                                            // a plane of padding zeros (workgroup-uniform)
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) outp[tid + kPlNT * u] = z;
+    return;
+  }
+  // pass-A twiddles of lane tseq: the same for the x rows and the y columns, requested once, ahead of the plane
+  f2 w[8];
+  passA_twiddle_fetch<G>(w, tseq, twA);
+  // ---- 1. the padded plane -> LDS (dword per lane, 256 contiguous bytes per wave-instruction; padding of both axes
+  // through the index maps, positions past the padded extent read as zero)
+  {
+    const float* plane = a.src + ((size_t)img * a.SZ + zs) * a.SY * a.SX;
+    const BufRsrc pr = make_rsrc(plane, (unsigned)(a.SY * a.SX * 4));
+    const int xp = tid & 63, xs = axis_src(a.mx, xp);
+    float val[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int yp = (tid >> 6) + 4 * u;
+      const int ys = axis_src(a.my, yp);
+      val[u] = buf_load_f32(pr, (ys >= 0 && xs >= 0) ? (unsigned)(ys * a.SX + xs) * 4u : 0xFFFFFFFFu, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) rowbuf[((tid >> 6) + 4 * u) * RP + xp] = val[u];
+  }
+  __syncthreads();
+  // ---- 2. x rows: rows 2sq and 2sq+1 ride one complex transform at odd frequencies (nd_passes.hpp, rows_r2c)
+  f2 v[8];
+#pragma unroll
+  for (int n1 = 0; n1 < 8; ++n1) {
+    const int x = 8 * n1 + tseq;
+    v[n1] = mk2(rowbuf[(2 * sq) * RP + x], rowbuf[(2 * sq + 1) * RP + x]);
+  }
+  {
+    float ws, wc;
+    sincospif(-(float)tseq / 64.0f, &ws, &wc);
+    const f2 wt = mk2(wc, ws);
+    static_for<0, 8>([&](auto ic) {
+      constexpr int n1 = decltype(ic)::value;
+      constexpr float c = (float)cospi_q(n1, 8), s = (float)sinpi_q(n1, 8);
+      v[n1] = cmul(v[n1], cmul_const(wt, c, -s));
+    });
+  }
+  fft_regs<8, -1>(v);
+  __syncthreads();                                         // every wave has read its rows: the region changes hands
+  f2* seq = reg + sq * kPlPitch;
+  passA_twiddle_apply<G, -1>(v, w, seq, tseq);
+  seq_sync<G>();
+  passB_load<G>(v, seq, tseq);
+  passB_compute<G, -1>(v, tseq, twB);                      // v[k] = bin tseq + 8k of the packed pair
+  // unpack the two real rows' spectra at bins fx = tseq + 8k < 32; the partner bin 63 - fx is element 7 - k of lane
+  // 7 - tseq of the same sequence: one DPP half-row mirror, no LDS
+  f2 ev[4], ov[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f2 zf = v[k];
+    const f2 zg = mk2(dpp_half_mirror(v[7 - k].x), dpp_half_mirror(v[7 - k].y));
+    ev[k] = mk2(0.5f * (zf.x + zg.x), 0.5f * (zf.y - zg.y));
+    ov[k] = mk2(0.5f * (zf.y + zg.y), 0.5f * (zg.x - zf.x));
+  }
+  __syncthreads();                                         // every x row is in registers
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    f4 q; q.x = ev[k].x; q.y = ev[k].y; q.z = ov[k].x; q.w = ov[k].y;
+    *reinterpret_cast<f4*>(reg + (tseq + 8 * k) * kPlPitch + 2 * sq) = q;     // [fx][y]: rows 2sq, 2sq+1
+  }
+  __syncthreads();
+  // ---- 3. y columns: sequence fx = sq, in place in its slot
+#pragma unroll
+  for (int n1 = 0; n1 < 8; ++n1) v[n1] = seq[8 * n1 + tseq];
+  fft_regs<8, -1>(v);
+  passA_twiddle_apply<G, -1>(v, w, seq, tseq);
+  seq_sync<G>();
+  passB_load<G>(v, seq, tseq);
+  passB_compute<G, -1>(v, tseq, twB);                      // v[k] = bin fy = tseq + 8k of column fx = sq
+  seq_sync<G>();                                           // (the slot is rewritten by its own eight lanes only)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) seq[tseq + 8 * k] = v[k];
+  __syncthreads();
+  // ---- 4. the plane's spectrum leaves as one contiguous 16 KB run, 16 bytes per lane
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int idx = tid + kPlNT * u, fx = idx >> 5, wq = idx & 31;
+    outp[idx] = *reinterpret_cast<const f4*>(reg + fx * kPlPitch + 2 * wq);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ planes_inv
+struct PlaneInvArgs {
+  const f2* src;         // O [(b*Cout + co)][NZo][2048]
+  float* dst;            // (B, Cout, Zo, Yo, Xo)
+  const float* bias;
+  const f2* twA;
+  const f2* twB;
+  int NZo, Cout;
+  int NVy, sy, Yo;       // valid stride-1 rows, decimation, output rows
+  int NVx, sx, Xo;
+};
+
+template <int NT_>
+__global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a) {
+  using G = Geo<8, 1>;
+  __shared__ __attribute__((aligned(16))) f2 reg[32 * kPlPitch];     // one region, six changes of hands (see planes_fwd)
+  constexpr int YP = 36;                                   // Yt[yo][fx] pitch (complex): row pairs land 64 bytes apart mod 256
+  static_assert(64 * YP <= 32 * kPlPitch, "transposed rows fit the region");
+  const BufRsrc twA = make_rsrc(a.twA, 8 * 8 * 8), twB = make_rsrc(a.twB, 8 * 8);
+  const int tid = threadIdx.x, sq = tid >> 3, tseq = tid & 7;
+  const int img = blockIdx.x / a.NZo, zi = blockIdx.x - img * a.NZo;
+  f2 w[8];
+  passA_twiddle_fetch<G>(w, tseq, twA);                    // one batch for both inverse passes, ahead of the plane
+  {
+    const f4* inp = reinterpret_cast<const f4*>(a.src + ((size_t)img * a.NZo + zi) * kPlCols);
+    f4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = inp[tid + kPlNT * u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + kPlNT * u, fx = idx >> 5, wq = idx & 31;
+      *reinterpret_cast<f4*>(reg + fx * kPlPitch + 2 * wq) = q[u];
+    }
+  }
+  float b = a.bias ? a.bias[img % a.Cout] : 0.f;
+  __syncthreads();
+  // ---- y columns back: sequence fx = sq; sample n = tseq + 8k
+  f2 v[8];
+  f2* seq = reg + sq * kPlPitch;
+  nat_load<G>(v, seq, tseq);
+  seq_sync<G>();
+  fft_regs<8, +1>(v);
+  passA_twiddle_apply<G, +1>(v, w, seq, tseq);
+  seq_sync<G>();
+  passB_load<G>(v, seq, tseq);
+  passB_compute<G, +1>(v, tseq, twB);
+  __syncthreads();                                         // every column is in registers
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int n = tseq + 8 * k, yo = n / a.sy;
+    if (n < a.NVy && yo * a.sy == n) reg[yo * YP + sq] = v[k];
+  }
+  __syncthreads();
+  // ---- x rows back: output rows 2sq (-> real part) and 2sq+1 (-> imaginary part) share one inverse transform
+  // (odd-frequency bins: V[f] = Ya[f] + i Yb[f], V[63-f] = conj(Ya[f]) + i conj(Yb[f]), f < 32; rows_c2r)
+  const int ra = 2 * sq, rb = ra + 1;
+  const bool has_a = ra < a.Yo, has_b = rb < a.Yo;
+  static_for<0, 8>([&](auto ic) {
+    constexpr int i1 = decltype(ic)::value;
+    const int f = 8 * i1 + tseq, fs = i1 < 4 ? f : 63 - f;
+    f2 ya = reg[ra * YP + fs], yb = reg[rb * YP + fs];
+    ya = has_a ? ya : mk2(0.f, 0.f);
+    yb = has_b ? yb : mk2(0.f, 0.f);
+    v[i1] = i1 < 4 ? mk2(ya.x - yb.y, ya.y + yb.x) : mk2(ya.x + yb.y, yb.x - ya.y);
+  });
+  fft_regs<8, +1>(v);
+  __syncthreads();                                         // every row pair has been read
+  passA_twiddle_apply<G, +1>(v, w, seq, tseq);
+  seq_sync<G>();
+  passB_load<G>(v, seq, tseq);
+  passB_compute<G, +1>(v, tseq, twB);                       // sample n = tseq + 8k
+  {
+    float ws, wc;
+    sincospif((float)tseq / 64.0f, &ws, &wc);
+    const f2 wb = mk2(wc, ws);
+    static_for<0, 8>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr float c = (float)cospi_q(k, 8), s = (float)sinpi_q(k, 8);
+      v[k] = cmul(v[k], cmul_const(wb, c, s));
+    });
+  }
+  __syncthreads();                                          // every exchange has been read: the region becomes the output plane
+  float* ob = reinterpret_cast<float*>(reg);                // [Yo][Xo]
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int n = tseq + 8 * k, xo = n / a.sx;
+    if (n < a.NVx && xo * a.sx == n) {
+      if (has_a) ob[ra * a.Xo + xo] = v[k].x + b;
+      if (has_b) ob[rb * a.Xo + xo] = v[k].y + b;
+    }
+  }
+  __syncthreads();
+  float* op = a.dst + ((size_t)img * a.NZo + zi) * a.Yo * a.Xo;
+  const int total = a.Yo * a.Xo;
+  for (int idx = tid; idx < total; idx += kPlNT) op[idx] = ob[idx];
+}
+
+// ------------------------------------------------------------------------------------------ colz
+struct ColZArgs {
+  const f2* src;         // S [(b*Cin + ci)][NZ][2048]
+  const f4* wspec;       // [g][Cog_pad][Cig_pad/2 = 4][2048][64] f4 = {H(o,2ip), H(o,2ip+1)}
+  f2* dst;               // O [(b*Cout + co)][NZo][2048]
+  int B, Cin, Cout, G, Cig, Cog, Cog_pad, cob, n_ochunks;
+  int NZ, NZo;           // planes per image on the signal / output side
+  int V, ntiles, Lfull, stride;     // overlap-save tiles along z (tile t: padded planes [t*V, t*V + 64))
+  unsigned long long* stamps;       // profiling build only: 8 timestamps (100 MHz) per workgroup
+};
+
+constexpr int colz_fc(int nb) { return nb >= 2 ? 16 : 8; }      // frequencies per exchange chunk
+constexpr size_t colz_lds_bytes(int nb) { return (size_t)2 * nb * 8 * 16 * (colz_fc(nb) + 1) * sizeof(f2); }
+
+// NB batch items per workgroup (1, 2 or 4) share every kernel-spectrum load.  A chunk of FC frequencies x 16 columns
+// is mixed by NB*128 threads: R = NB*8/FC threads per bin, each owning 8/R output channels (with NB = 4 the two
+// halves of the workgroup).  RING spectrum sets (one output channel x 8 inputs = 4 float4) travel per thread.
+template <int NB, int RING, bool STAMPS = false>
+__global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
+  constexpr int NT = NB * 128;
+  constexpr int FC = colz_fc(NB);
+  constexpr int R = NT / (16 * FC);         // threads per bin
+  constexpr int SPC = 8 / R;                // mix steps (output channels) per thread and chunk
+  constexpr int NCH = 64 / FC;
+  constexpr int PF = FC + 1;                // padded chunk rows: conflict-free for lanes over columns AND over frequencies
+  constexpr int ROW = 16 * PF;              // complex slots per (batch slot, channel)
+  static_assert(R * FC * 16 == NT && NCH * FC == 64 && SPC * R == 8, "bins, threads and output channels divide evenly");
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  f2* xs = lds;                             // [NB*8][16][PF] forward spectra of the chunk
+  f2* ys = lds + NB * 8 * ROW;              // [NB*8][16][PF] mixed spectra of the chunk
+  const int tid = threadIdx.x;
+  auto stampc = [&](int slot, bool drain) {
+    if constexpr (STAMPS) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  stampc(0, false);
+  // XCD-aware unit map (see fusedc): workgroups that stream one block of the kernel spectrum sit on one XCD (equal
+  // blockIdx % 8) and run back to back (the batch block is the fastest index behind it)
+  int id = blockIdx.x;
+  const int xcd = id & 7; id >>= 3;
+  const int nbp = (a.B + NB - 1) / NB;
+  const int b0 = (id % nbp) * NB; id /= nbp;
+  const int colblk = xcd * (kPlCols / 128) + id % (kPlCols / 128); id /= (kPlCols / 128);
+  const int g = id % a.G; id /= a.G;
+  const int oc = id % a.n_ochunks;
+  const int tile = id / a.n_ochunks;
+  const int col0 = colblk * 16;
+  const int nbc = min(NB, a.B - b0);
+  const int t0 = tile * a.V;
+  // (plane step of the 64 loads / stores as an opaque scalar: as 64 literal offsets hipcc keeps every one of them in
+  // its own SGPR across the kernel and spills)
+  unsigned zstep = kPlCols * 8;
+  asm volatile("" : "+s"(zstep));
+
+  // ---- sequence owner: (batch slot nb, channel ch, column c)
+  const int c = tid & 15, ch = (tid >> 4) & 7, nb = tid >> 7;
+  f2 v[64];
+  // (the output resource is built here, while scalar registers are plentiful: built behind the transforms, whose
+  // twiddle constants fill the SGPR file, hipcc assembled it in VECTOR registers and wrapped every store in a
+  // readfirstlane loop)
+  const int cend = min(a.cob, a.Cog - oc * a.cob);
+  f2* obase = a.dst + ((size_t)b0 * a.Cout + (size_t)g * a.Cog + (size_t)oc * a.cob) * a.NZo * kPlCols;
+  const BufRsrc orr = make_rsrc(obase, (unsigned)((((size_t)(nbc - 1) * a.Cout + cend) * a.NZo) * kPlCols * 8));
+  {
+    const f2* sbase = a.src + ((size_t)b0 * a.Cin + (size_t)g * a.Cig) * a.NZ * kPlCols;
+    const BufRsrc sr = make_rsrc(sbase, (unsigned)((((size_t)(nbc - 1) * a.Cin + a.Cig) * a.NZ) * kPlCols * 8));
+    const bool has_in = ch < a.Cig && nb < nbc;
+    // (dead loads / stores: bit 31 of the offset -- every resource here is below 2 GiB, fc_api.cpp plan_nd -- which,
+    // unlike an all-ones offset, cannot wrap back into range when the instruction's constant offset is added)
+    const unsigned voff = has_in ? (unsigned)((((size_t)nb * a.Cin + ch) * a.NZ + t0) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    if (t0 + 64 <= a.NZ) {                                  // (the usual case without a select per load)
+      static_for<0, 64>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        v[n] = buf_load_f32x2(sr, voff, n * zstep);
+      });
+    } else {
+      static_for<0, 64>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        v[n] = buf_load_f32x2(sr, (t0 + n < a.NZ) ? voff : 0x80000000u, n * zstep);
+      });
+    }
+  }
+  // ---- bin owner: (share h of the output channels, frequency fzl of the chunk, column cm); its kernel-spectrum
+  // stream does not depend on data
+  const int h = tid / (16 * FC), fzl = tid % FC, cm = (tid / FC) % 16;
+  const size_t wrow = (size_t)kPlCols * 64;                 // f4 per (o, ip)
+  const f4* wbase = a.wspec + ((size_t)g * a.Cog_pad + (size_t)oc * a.cob) * 4 * wrow;
+  const BufRsrc wr_ = make_rsrc(wbase, (unsigned)((size_t)a.cob * 4 * wrow * 16));
+  // (lane offset: column, frequency and this thread's first output channel h*SPC -- at most 64 MB)
+  const unsigned wvo = (unsigned)((col0 + cm) * 64 + fzl) * 16u + (unsigned)(h * SPC * 4) * (unsigned)(kPlCols * 64 * 16);
+  f4 ring[RING][4];
+  auto issue = [&](auto stc) {
+    constexpr int st = decltype(stc)::value;
+    constexpr int chunk = st / SPC, k = st % SPC;
+    // (rows past the chunk's last output channel lie outside the spectrum buffer: the scalar offset is not part of
+    // the range check, so those loads are switched off through the lane offset)
+    const unsigned vo = h * SPC + k < a.cob ? wvo + (unsigned)(chunk * FC * 16) : 0x80000000u;
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip)
+      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (kPlCols * 64 * 16)));
+  };
+  // (the first sets travel during the forward transform, whose temporaries leave room for two of them)
+  constexpr int EARLY = RING < 2 ? RING : 2;
+  static_for<0, EARLY>([&](auto sc) { issue(sc); });
+  stampc(1, true);
+  fft_regs<64, -1>(v);                                      // 64-point forward transform along z, in registers
+  static_for<EARLY, RING>([&](auto sc) { issue(sc); });
+  stampc(2, false);
+
+  static_for<0, NCH>([&](auto cc) {
+    constexpr int chunk = decltype(cc)::value;
+    {
+      f2* xrow = xs + ((nb * 8 + ch) * 16 + c) * PF;
+#pragma unroll
+      for (int j = 0; j < FC; ++j) xrow[j] = v[chunk * FC + j];
+    }
+    __syncthreads();
+    {
+      const unsigned xa = lds_off(xs + cm * PF + fzl);
+      f2* yrow = ys + cm * PF + fzl;
+      // two batch items at a time: their inputs (16 reads in flight together) and two interleaved accumulation chains
+      // (a chain of dependent v_pk_fma_f32 issues every 8 cycles, two of them every 4)
+      constexpr int NP = NB >= 2 ? NB / 2 : 1, PB = NB >= 2 ? 2 : 1;
+      f2 x[PB][8];
+      auto load_x = [&](auto pc) {
+        constexpr int pr = decltype(pc)::value;
+        static_for<0, PB>([&](auto bc) {
+          constexpr int bb = pr * PB + decltype(bc)::value;
+          static_for<0, 8>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            x[decltype(bc)::value][i] = lds_rd_far<(bb * 8 + i) * ROW * 8>(xa);
+          });
+        });
+#pragma unroll
+        for (int q = 0; q < PB; ++q) lds_arrive(x[q]);
+      };
+      if constexpr (NP == 1) load_x(std::integral_constant<int, 0>{});      // held across the chunk's output channels
+      static_for<0, SPC>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int st = chunk * SPC + k;
+        f4 (&w)[4] = ring[st % RING];
+        const int o = h * SPC + k;
+        if (o < a.cob) {
+          static_for<0, NP>([&](auto pc) {
+            constexpr int pr = decltype(pc)::value;
+            if constexpr (NP > 1) load_x(pc);
+            f2 y[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) y[q] = mk2(0.f, 0.f);
+#pragma unroll
+            for (int ip = 0; ip < 4; ++ip) {
+#pragma unroll
+              for (int q = 0; q < PB; ++q) cmac(y[q], x[q][2 * ip], w[ip].xy);
+#pragma unroll
+              for (int q = 0; q < PB; ++q) cmac(y[q], x[q][2 * ip + 1], w[ip].zw);
+            }
+#pragma unroll
+            for (int q = 0; q < PB; ++q) yrow[((pr * PB + q) * 8 + o) * ROW] = y[q];
+          });
+        }
+        if constexpr (st + RING < NCH * SPC) issue(std::integral_constant<int, st + RING>{});
+      });
+    }
+    __syncthreads();
+    {
+      const f2* yrow = ys + ((nb * 8 + ch) * 16 + c) * PF;
+#pragma unroll
+      for (int j = 0; j < FC; ++j) v[chunk * FC + j] = yrow[j];
+    }
+  });
+  stampc(3, false);
+  fft_regs<64, +1>(v);                                      // back along z (the 1/N factors live in the kernel spectrum)
+  stampc(4, false);
+  {
+    const bool live = nb < nbc && ch < a.cob && oc * a.cob + ch < a.Cog;
+    const int limit = min(a.V, a.Lfull - t0);
+    const unsigned vo = live ? (unsigned)((((size_t)nb * a.Cout + ch) * a.NZo) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    if (a.stride == 1) {
+      unsigned zstep_st = kPlCols * 8;               // (a copy of its own: shared with the loads, the 64 products stay live in SGPRs)
+      asm volatile("" : "+s"(zstep_st));
+      const unsigned vo1 = live ? vo + (unsigned)t0 * (kPlCols * 8) : 0x80000000u;
+      // blocks of 8 planes: a block inside the valid window is straight-line code behind one scalar branch
+      static_for<0, 8>([&](auto bc) {
+        constexpr int n0 = 8 * decltype(bc)::value;
+        if (n0 + 8 <= limit) {
+          static_for<n0, n0 + 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            buf_store_f32x2(v[n], orr, vo1, n * zstep_st);
+          });
+        } else if (n0 < limit) {
+          static_for<n0, n0 + 8>([&](auto nc) {
+            constexpr int n = decltype(nc)::value;
+            buf_store_f32x2(v[n], orr, n < limit ? vo1 : 0x80000000u, n * zstep_st);
+          });
+        }
+      });
+    } else {
+      static_for<0, 64>([&](auto nc) {
+        constexpr int n = decltype(nc)::value;
+        const int t = t0 + n, idx = t / a.stride;
+        const bool ok = live && n < limit && idx * a.stride == t;
+        buf_store_f32x2(v[n], orr, ok ? vo + (unsigned)idx * (kPlCols * 8) : 0x80000000u, 0);
+      });
+    }
+  }
+  stampc(5, false);
+  stampc(6, true);
+  stampc(7, false);
+}
+
+}  // namespace fc

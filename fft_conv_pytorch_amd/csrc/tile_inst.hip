@@ -334,6 +334,45 @@ hipError_t dense_spec_dispatch(const DenseSpecArgs& a, hipStream_t st) {
 }
 #endif
 
+#if FC_P == 8 && FC_S == 1
+// plane-major 3-D pipeline: 64-point transforms on all three axes
+hipError_t planes_fwd_dispatch(const PlaneFwdArgs& a, int n_images, hipStream_t st) {
+  const long long grid = (long long)n_images * a.NZ;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(planes_fwd_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
+  return hipGetLastError();
+}
+hipError_t planes_inv_dispatch(const PlaneInvArgs& a, int n_images, hipStream_t st) {
+  const long long grid = (long long)n_images * a.NZo;
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
+  return hipGetLastError();
+}
+template <int NB, bool STAMPS = false>
+hipError_t launch_colz(const ColZArgs& a, hipStream_t st) {
+  constexpr int RING = NB == 4 ? 3 : 2;
+  auto k = colz_kernel<NB, RING, STAMPS>;
+  const size_t lds = colz_lds_bytes(NB);
+  static LdsOptIn done;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  const long long nbp = (a.B + NB - 1) / NB;
+  const long long grid = nbp * a.ntiles * a.n_ochunks * a.G * (kPlCols / 16);
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB * 128), lds, st, a);
+  return hipGetLastError();
+}
+// batch items per workgroup: 2 (two workgroups per CU).  4 (one 512-thread workgroup per CU, half the spectrum traffic,
+// FFTCONV_COLZ_NB=4) measured slower at cfgC: mix 28.4 against 21.2 us per workgroup -- its inputs no longer stay in
+// registers across the output channels and the mix waits on LDS round trips instead (profiles/r03_experiments.md)
+hipError_t colz_dispatch(const ColZArgs& a, hipStream_t st) {
+  static const int force = getenv("FFTCONV_COLZ_NB") ? atoi(getenv("FFTCONV_COLZ_NB")) : 0;
+  const int nb = (force == 1 || force == 2 || force == 4) ? force : (a.B >= 2 ? 2 : 1);
+  if (a.stamps) return nb == 4 ? launch_colz<4, true>(a, st) : (nb == 2 ? launch_colz<2, true>(a, st) : launch_colz<1, true>(a, st));
+  return nb == 4 ? launch_colz<4>(a, st) : (nb == 2 ? launch_colz<2>(a, st) : launch_colz<1>(a, st));
+}
+#endif
+
 }  // namespace
 
 #define FC_CAT_(a, b, c, d) a##b##c##d
@@ -353,9 +392,14 @@ const TileImpl* FC_CAT(get_tile_P, FC_P, _S, FC_S)() {
 #endif
                                 kWgradNb,
 #if FC_P == 32 && (FC_S == 1 || FC_S == 2)
-                                dense_dispatch, dense_spec_dispatch
+                                dense_dispatch, dense_spec_dispatch,
 #else
-                                nullptr, nullptr
+                                nullptr, nullptr,
+#endif
+#if FC_P == 8 && FC_S == 1
+                                planes_fwd_dispatch, colz_dispatch, planes_inv_dispatch
+#else
+                                nullptr, nullptr, nullptr
 #endif
   };
   return &impl;

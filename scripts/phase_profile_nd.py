@@ -35,6 +35,8 @@ st = buf.cpu().numpy().reshape(grid, 8).astype(np.float64) * 0.01   # 100 MHz ti
 st = st[st[:, 7] > 0]
 t0 = st[:, 0].min()
 names = ["start", "input landed", "fwd FFT done", "barrier", "mix done", "barrier", "inverse FFT done", "stores landed"]
+if args.nd == 3 and os.environ.get("FFTCONV_PLANES", "1") != "0" and args.size <= 64:   # colz (planes3d.hpp)
+    names = ["start", "input landed", "fwd FFT done", "mix done", "inverse FFT done", "stores issued", "stores landed", "-"]
 print(f"workgroups={len(st)} tile={plan.tile}  kernel span = {st[:, 7].max() - t0:.2f} us")
 for i in range(1, 8):
     dt = st[:, i] - st[:, i - 1]

@@ -17,12 +17,13 @@ LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, LIB_NAME)   # en
 
 FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
 PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
     "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_plan_layout", "fc_transform_kernel",
-    "fc_forward", "fc_forward_stamped", "fc_wgrad1d_slices", "fc_wgrad1d", "fc_debug_grid",
+    "fc_forward", "fc_forward_stamped", "fc_wgrad1d_slices", "fc_wgrad1d", "fc_wgrad1d_db", "fc_wgrad1d_db_supported",
+    "fc_debug_grid",
 )
 
 
@@ -84,6 +85,10 @@ def load_library() -> ctypes.CDLL:
         lib.fc_wgrad1d_slices.restype = i32
         lib.fc_wgrad1d.argtypes = [ctypes.POINTER(FcDesc), vp, vp, vp, i32, vp]
         lib.fc_wgrad1d.restype = i32
+        lib.fc_wgrad1d_db.argtypes = [ctypes.POINTER(FcDesc), vp, vp, vp, vp, ctypes.c_longlong, i32, vp]
+        lib.fc_wgrad1d_db.restype = i32
+        lib.fc_wgrad1d_db_supported.argtypes = [ctypes.POINTER(FcDesc)]
+        lib.fc_wgrad1d_db_supported.restype = i32
         lib.fc_forward_stamped.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         lib.fc_forward_stamped.restype = i32
         lib.fc_plan_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32 * 8)]
@@ -120,6 +125,19 @@ def wgrad1d_slices(desc: FcDesc) -> int:
 def wgrad1d(desc: FcDesc, x_ptr: int, dy_ptr: int, partial_ptr: int, slices: int, stream: int):
     lib = load_library()
     st = lib.fc_wgrad1d(ctypes.byref(desc), x_ptr, dy_ptr, partial_ptr, slices, stream)
+    if st != FC_OK:
+        _raise(lib, st)
+
+
+def wgrad1d_db_supported(desc: FcDesc) -> bool:
+    return bool(load_library().fc_wgrad1d_db_supported(ctypes.byref(desc)))
+
+
+def wgrad1d_db(desc: FcDesc, x_ptr: int, dy_ptr: int, partial_ptr: int, db_ptr: Optional[int], slice_stride: int,
+               slices: int, stream: int):
+    """fc_wgrad1d with the bias gradient folded in: rows [dW | db] of ``slice_stride`` floats per slice."""
+    lib = load_library()
+    st = lib.fc_wgrad1d_db(ctypes.byref(desc), x_ptr, dy_ptr, partial_ptr, db_ptr, slice_stride, slices, stream)
     if st != FC_OK:
         _raise(lib, st)
 

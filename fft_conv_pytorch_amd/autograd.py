@@ -29,28 +29,59 @@ _DW_TILE = 2048      # FFT tile the dW correlation is sized for: the largest one
                      # accumulating (> 8 channels', i.e. batch > 8) mode of the fused kernel in LDS
 
 
+_BWD_PLANS: dict = {}      # (shapes, hyper-parameters, device) -> (transposed plan of dX, ...): skips the argument
+                           # normalisation and descriptor lookup of the functional on every backward call
+
+
+def _pad_adjoint(dxp: Tensor, in_spatial, padding, mode: str) -> Tensor:
+    """Adjoint of ``F.pad(x, padding, mode)`` for reflect / replicate / circular: fold the border samples of the
+    gradient w.r.t. the padded signal back onto their sources, one axis after the other (the padding is separable).
+    A handful of slice-adds on border planes; the round-2 version back-propagated through torch's own pad with a
+    zeros probe per call."""
+    t = dxp
+    for i, (n, p) in enumerate(zip(in_spatial, padding)):
+        ax = 2 + i
+        if p == 0:
+            continue
+        core = t.narrow(ax, p, n).clone()
+        left, right = t.narrow(ax, 0, p), t.narrow(ax, n + p, p)
+        if mode == "reflect":          # padded j < p reads source p - j; padded n + p + j reads source n - 2 - j
+            core.narrow(ax, 1, p).add_(left.flip(ax))
+            core.narrow(ax, n - 1 - p, p).add_(right.flip(ax))
+        elif mode == "replicate":
+            core.narrow(ax, 0, 1).add_(left.sum(dim=ax, keepdim=True))
+            core.narrow(ax, n - 1, 1).add_(right.sum(dim=ax, keepdim=True))
+        elif mode == "circular":       # padded j < p reads source n - p + j; padded n + p + j reads source j
+            core.narrow(ax, n - p, p).add_(left)
+            core.narrow(ax, 0, p).add_(right)
+        else:
+            raise ValueError(f"no adjoint for padding mode {mode!r}")
+        t = core
+    return t.contiguous()
+
+
 def _grad_input(grad: Tensor, weight: Tensor, in_spatial, stride, padding, dilation, groups, padding_mode) -> Tensor:
     n = grad.ndim - 2
-    pad_t = padding if padding_mode == "constant" else (0,) * n
-    full = tuple(s + 2 * (p if padding_mode != "constant" else 0) for s, p in zip(in_spatial, padding))
-    out_pad = []
-    for i in range(n):
-        base = (grad.shape[2 + i] - 1) * stride[i] - 2 * pad_t[i] + dilation[i] * (weight.shape[2 + i] - 1) + 1
-        out_pad.append(full[i] - base)
-    # conv weight (Cout, Cin/g, *k) is exactly the transposed-conv layout (Cin_t = Cout, Cout_t/g = Cin/g)
-    dx = F_.fft_conv_transpose(grad, weight, None, stride=stride, padding=pad_t, output_padding=tuple(out_pad),
-                               dilation=dilation, groups=groups)
+    key = ("dx", tuple(grad.shape), tuple(weight.shape), tuple(in_spatial), stride, padding, dilation, groups, padding_mode,
+           grad.device, grad.dtype)
+    plan = _BWD_PLANS.get(key)
+    if plan is None:
+        pad_t = padding if padding_mode == "constant" else (0,) * n
+        full = tuple(s + 2 * (p if padding_mode != "constant" else 0) for s, p in zip(in_spatial, padding))
+        out_pad = []
+        for i in range(n):
+            base = (grad.shape[2 + i] - 1) * stride[i] - 2 * pad_t[i] + dilation[i] * (weight.shape[2 + i] - 1) + 1
+            out_pad.append(full[i] - base)
+        # conv weight (Cout, Cin/g, *k) is exactly the transposed-conv layout (Cin_t = Cout, Cout_t/g = Cin/g)
+        plan = F_._plan_for(grad, weight, None, stride, pad_t, dilation, groups, "constant", transposed=True,
+                            output_padding=tuple(out_pad))
+        if len(_BWD_PLANS) > 256:
+            _BWD_PLANS.clear()
+        _BWD_PLANS[key] = plan
+    dx = F_._forward_native(grad, F_.transform_kernel(plan, weight), None)
     if padding_mode == "constant":
         return dx
-    # adjoint of the non-zero padding: let torch back-propagate through its own pad (data movement)
-    flat = []
-    for p in reversed(padding):
-        flat += [p, p]
-    with torch.enable_grad():       # backward() runs with grad mode off
-        probe = torch.zeros((dx.shape[0], dx.shape[1]) + tuple(in_spatial), device=dx.device, dtype=dx.dtype,
-                            requires_grad=True)
-        padded = F.pad(probe, flat, mode=padding_mode)
-    return torch.autograd.grad(padded, probe, dx)[0]
+    return _pad_adjoint(dx, in_spatial, padding, padding_mode)
 
 
 def _grad_weight_plans(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
@@ -102,32 +133,50 @@ def _grad_weight_plans(x: Tensor, grad: Tensor, wshape, stride, padding, dilatio
     return out[index].transpose(0, 1).contiguous()                  # (g*Cog, Cig, *k)
 
 
-def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode):
-    """dW by ``fc_wgrad1d`` (cross-spectra accumulated on chip over batch and row); None when not covered."""
+def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode,
+                        want_db: bool = False):
+    """dW by ``fc_wgrad1d`` (cross-spectra accumulated on chip over batch and row); None when not covered.  With
+    ``want_db`` the bias gradient rides the same launch where the kernel offers it (bin 0 of the gradient spectra):
+    the slices come as rows [dW | db] and ONE reduction sums both.  Returns (dW, db or None)."""
     if x.ndim != 3 or x.dtype != torch.float32:      # (float64 runs the direct kernel: dW through forward plans)
         return None
     from . import _native
-    desc = _native.conv_desc(1, x.shape[0], x.shape[1], wshape[0], groups, (x.shape[2],), (wshape[2],), stride, padding,
-                             dilation, _native.PAD_MODES[padding_mode])
     if grad.device != x.device:
         raise ValueError(f"gradient is on {grad.device} but the signal is on {x.device}")
-    # the library sizes the launch for, and keeps its twiddle tables on, the CURRENT device
+    key = ("dw", tuple(x.shape), tuple(wshape), stride, padding, dilation, groups, padding_mode, x.device)
+    hit = _BWD_PLANS.get(key)
+    if hit is None:
+        desc = _native.conv_desc(1, x.shape[0], x.shape[1], wshape[0], groups, (x.shape[2],), (wshape[2],), stride, padding,
+                                 dilation, _native.PAD_MODES[padding_mode])
+        # the library sizes the launch for, and keeps its twiddle tables on, the CURRENT device
+        with torch.cuda.device(x.device):
+            slices = _native.wgrad1d_slices(desc)
+            db_ok = bool(slices) and _native.wgrad1d_db_supported(desc)
+        hit = (desc, slices, db_ok)
+        if len(_BWD_PLANS) > 256:
+            _BWD_PLANS.clear()
+        _BWD_PLANS[key] = hit
+    desc, slices, db_ok = hit
+    if slices == 0:
+        return None
+    with_db = want_db and db_ok
+    n_w = wshape[0] * wshape[1] * wshape[2]
+    row = n_w + (wshape[0] if with_db else 0)
+    x = x.contiguous()
+    grad = grad.contiguous()
     with torch.cuda.device(x.device):
-        slices = _native.wgrad1d_slices(desc)
-        if slices == 0:
-            return None
-        x = x.contiguous()
-        grad = grad.contiguous()
-        part = torch.empty((slices,) + tuple(wshape), device=x.device, dtype=torch.float32)
-        _native.wgrad1d(desc, x.data_ptr(), grad.data_ptr(), part.data_ptr(), slices,
-                        torch.cuda.current_stream(x.device).cuda_stream)
-    return part[0] if slices == 1 else part.sum(dim=0)
+        part = torch.empty((slices, row), device=x.device, dtype=torch.float32)
+        _native.wgrad1d_db(desc, x.data_ptr(), grad.data_ptr(), part.data_ptr(),
+                           part.data_ptr() + 4 * n_w if with_db else None, row, slices,
+                           torch.cuda.current_stream(x.device).cuda_stream)
+    total = part[0] if slices == 1 else part.sum(dim=0)
+    return total[:n_w].view(wshape), (total[n_w:] if with_db else None)
 
 
 def _grad_weight(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
     native = _grad_weight_native(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
     if native is not None:
-        return native
+        return native[0]
     return _grad_weight_plans(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
 
 
@@ -153,10 +202,16 @@ class FFTConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             d_signal = _grad_input(grad, kernel.detach(), tuple(signal.shape[2:]), stride, padding, dilation, groups,
                                    padding_mode)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            d_kernel = _grad_weight(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation, groups,
-                                    padding_mode)
-        if has_bias and ctx.needs_input_grad[2]:
+            native = _grad_weight_native(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation, groups,
+                                         padding_mode, want_db)
+            if native is not None:
+                d_kernel, d_bias = native          # (db rode the weight-gradient launch where the kernel offers it)
+            else:
+                d_kernel = _grad_weight_plans(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation,
+                                              groups, padding_mode)
+        if want_db and d_bias is None:
             d_bias = grad.sum(dim=[0] + list(range(2, grad.ndim)))
         return d_signal, d_kernel, d_bias, None, None, None, None, None, None
 

@@ -49,8 +49,6 @@ struct Conv1dArgs {
   int pos_shift;         // kernel segment: its first tap sits this many samples into the (dilated) kernel
   int add_out;           // 1: y += result (later chunk launches of such a plan; bias went with the first)
   unsigned long long* stamps;  // optional profiling hook: 16 timestamps per workgroup (null = off)
-  int exp_stagger;       // tuning knob (FFTCONV_STAGGER, batch-sharing kernel): workgroups past the first `exp_stagger_from`
-  int exp_stagger_from;  // sleep this many units of 64 cycles before their first item (0 = off)
 };
 
 // Branch-free padded load.  Outside [0, L) the index is remapped as a*pos + b with

@@ -498,9 +498,6 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   const WorkItem w0 = pa.items[it0];
   const WorkItem w1 = pa.items[two ? it1 : it0];
   f2 va[P], vb[P];
-  if (a.exp_stagger > 0 && (int)blockIdx.x >= a.exp_stagger_from) {
-    for (int s = 0; s < a.exp_stagger; s += 16) __builtin_amdgcn_s_sleep(16);
-  }
   fetch(w0, va);                             // first item's samples and the twiddle table travel together
   copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
   __syncthreads();

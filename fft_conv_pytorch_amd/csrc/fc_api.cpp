@@ -287,8 +287,17 @@ static int plan_1d_inner(fc_plan* p) {
     if (want_dense && pays && dt && dt->dense && p->nseg == 1 && p->CB == 8 && p->Cig >= 16 && p->Cog >= 16 && d.stride[0] == 1 &&
         p->up[0] == 1 && !p->diag && !p->bd_gs && Kd <= 1537 && (!forced_tile || forced_tile == dT) &&
         (int64_t)p->Cig * d.spatial[0] * 4 < ((int64_t)1 << 32)) {
-      p->dense = 1;
-      forced_tile = dT;
+      // 32-bit offsets of the pipeline: dense_inv marks dead stores with bit 31 of an offset into one group's output rows
+      // (Cog * Lout * 4 bytes), and the slab resources / bin strides are 32-bit too (a slab row block of at least 128
+      // rows x NF bins x max(Kc, Nc) channels).  Shapes beyond either limit stay with the fused kernels.
+      const int64_t NFd = dT / 2 + 1;
+      const int64_t rows_min = std::min<int64_t>(Md, 128);
+      const bool out_ok = (int64_t)p->Cog * p->out_sp[0] * 4 < ((int64_t)1 << 31);
+      const bool slab_ok = NFd * rows_min * std::max(p->Cig_pad, p->Cog_pad) * 8 < ((int64_t)1 << 32);
+      if (out_ok && slab_ok) {
+        p->dense = 1;
+        forced_tile = dT;
+      }
     }
   }
   if (!p->dense) {
@@ -376,6 +385,8 @@ static int plan_1d_inner(fc_plan* p) {
     const size_t row_bytes = (size_t)p->G * NF * (size_t)(p->Cig_pad + p->Cog_pad) * sizeof(fc::f2);
     int64_t slab = (int64_t)(((size_t)192 << 20) / row_bytes) / 128 * 128;
     slab = std::max<int64_t>(128, slab);
+    // (32-bit offsets inside a slab: NF * rows * channels * 8 bytes per side; plan_1d_inner admitted the shape for 128 rows)
+    while (slab > 128 && (int64_t)NF * slab * std::max(p->Cig_pad, p->Cog_pad) * 8 >= ((int64_t)1 << 32)) slab -= 128;
     if (const char* e = getenv("FFTCONV_DENSE_SLAB")) slab = std::max(1, atoi(e));     // testing knob: rows per slab
     p->dense_mslab = (int)std::min<int64_t>(M, slab);
     p->dense_cus = 256;
@@ -827,7 +838,8 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   if (n_items > 0x3fffffff) return 0;
   int cus = 256;
   if (!current_device_cus(&cus)) return 0;
-  static const bool diag_on = !getenv("FFTCONV_DIAG") || atoi(getenv("FFTCONV_DIAG")) != 0;
+  const char* diag_env = getenv("FFTCONV_DIAG");        // read per call, like the plan-creation knobs (not frozen at first use)
+  const bool diag_on = !diag_env || atoi(diag_env) != 0;
   g->diag = diag_on && d.groups == d.in_channels && d.groups == d.out_channels && d.groups % 8 == 0 &&
             t->wgrad1d_diag != nullptr;
   const int nb = g->diag ? 1 : t->wgrad_nb;
@@ -856,10 +868,28 @@ int fc_wgrad1d_slices(const fc_desc* desc) {
   return g.slices;
 }
 
+int fc_wgrad1d_db_supported(const fc_desc* desc) {
+  if (!desc) return 0;
+  WgradGeom g;
+  return wgrad_geometry(*desc, &g) && !g.diag;
+}
+
 int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream) {
+  return fc_wgrad1d_db(desc, x, dy, partial, nullptr, 0, slices, hip_stream);
+}
+
+int fc_wgrad1d_db(const fc_desc* desc, const float* x, const float* dy, float* partial, float* db_partial,
+                  long long slice_stride, int slices, void* hip_stream) {
   if (!desc || !x || !dy || !partial) return fail(FC_ERR_INVALID, "null argument");
   WgradGeom g;
   if (!wgrad_geometry(*desc, &g)) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad1d does not cover this shape");
+  if (db_partial && g.diag) return fail(FC_ERR_UNSUPPORTED, "the depthwise weight-gradient kernel has no bias-gradient output "
+                                        "(ask fc_wgrad1d_db_supported first)");
+  {
+    const long long dense = (long long)desc->out_channels * (desc->in_channels / desc->groups) * desc->kernel[0];
+    if (slice_stride == 0) slice_stride = dense;
+    if (slice_stride < dense) return fail(FC_ERR_INVALID, "slice_stride %lld is smaller than one partial tensor (%lld floats)", slice_stride, dense);
+  }
   if (slices != g.slices) return fail(FC_ERR_INVALID, "partial holds %d slices, the plan needs %d", slices, g.slices);
   Twiddles tw;
   int rc = find_twiddles(g.t, &tw);
@@ -876,12 +906,14 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
   a.n_items = g.n_items; a.items_per_slice = g.ipw; a.nob = g.nob; a.nib = g.nib;
   a.scale = 1.0f / (4.0f * (float)g.t->T);
   a.Krow = (int)d.kernel[0];
+  a.part_stride = slice_stride;
   const int64_t grid = g.diag ? (int64_t)g.slices * (d.groups / 8) : (int64_t)g.slices * d.groups * g.nob * g.nib;
   if (grid > 0x7fffffff) return fail(FC_ERR_UNSUPPORTED, "grid too large");
   for (int j = 0; j < g.nseg; ++j) {
     a.tap0 = j * g.seg_taps;
     a.K = std::min(g.seg_taps, (int)d.kernel[0] - a.tap0);
     a.pos_shift = a.tap0 * (int)d.dilation[0];
+    a.dbpart = j == 0 ? db_partial : nullptr;      // every segment sees all of dY: the bias gradient comes from the first
     if (g.diag) FC_HIP(g.t->wgrad1d_diag(a, (int)grid, (hipStream_t)hip_stream));
     else FC_HIP(g.t->wgrad1d(a, (int)grid, (hipStream_t)hip_stream));
   }
@@ -937,6 +969,11 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
     a.nseq = a.G * a.Cog_pad * (a.Cig_pad / 2);
     a.transposed = p.d.transposed;
     a.Krow = (int)p.d.kernel[0];
+    {
+      const unsigned long long wb = 4ull * (unsigned long long)(p.d.transposed ? p.d.in_channels : p.d.out_channels) *
+                                    (unsigned long long)((p.d.transposed ? p.d.out_channels : p.d.in_channels) / p.d.groups) * (unsigned long long)p.d.kernel[0];
+      a.w_bytes = wb < 0x7F000000ull ? (unsigned)wb : 0u;   // (dead offsets are bit 31 minus at most a few KB: they must stay outside)
+    }
     const int per_wg = p.tile->NT / (p.tile->P * p.tile->S);
     const int grid = (a.nseq + per_wg - 1) / per_wg;
     if (p.dense) {
@@ -1062,11 +1099,6 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     a.stride = p.ostride[0]; a.accumulate = p.accumulate;
     a.ic_begin = 0; a.ic_end = p.Cig_pad / p.CB; a.add_out = 0;
     a.stamps = (unsigned long long*)stamps;
-    {
-      static const int stagger = getenv("FFTCONV_STAGGER") ? atoi(getenv("FFTCONV_STAGGER")) : 0;   // tuning knob
-      static const int stagger_from = getenv("FFTCONV_STAGGER_FROM") ? atoi(getenv("FFTCONV_STAGGER_FROM")) : 256;
-      a.exp_stagger = stagger; a.exp_stagger_from = stagger_from;
-    }
     a.segmented = p.nseg > 1; a.pos_shift = 0;
     if (p.pers_nb) {
       for (int j = 0; j < p.nseg; ++j) {

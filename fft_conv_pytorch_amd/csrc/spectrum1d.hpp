@@ -23,6 +23,7 @@ struct Spec1dArgs {
                        // (C, gs, K) weight tensor; entries that cross a group stay zero
   int Krow, k0;        // taps per weight row and first tap of this kernel segment (K = taps of the segment)
   int transposed;      // kernel is (Cin, Cout/g, K): swap in/out inside the group and flip the taps
+  unsigned w_bytes;    // size of the weight tensor when it is below 2 GiB (branch-free buffer loads), else 0
 };
 
 template <int P, int S, int NT>
@@ -61,14 +62,46 @@ __global__ __launch_bounds__(NT) void spectrum1d_kernel(const Spec1dArgs a) {
       w1 = w0 + (a.transposed ? (size_t)a.gs * a.Krow : (size_t)a.Krow);
       if (!same) { w0 = a.w; w1 = a.w; }
     }
+    if (a.w_bytes != 0) {
+      // every tap of the thread requested at once through a buffer resource over the weight tensor: a missing tap (zero
+      // padding, dilation gap, phantom channel) is an offset outside it.  Written as `hit ? w[ts] : 0` each of the 2*P
+      // loads sat in its own branch behind a full wait -- 64 memory latencies in a row were the 10 us of this kernel.
+      const BufRsrc wr = make_rsrc(a.w, a.w_bytes);
+      const unsigned o0 = (unsigned)((w0 - a.w) * 4), o1 = (unsigned)((w1 - a.w) * 4);
+      if (a.dil == 1) {
+        // undilated (the usual case): tap = position, no emulated integer division per tap (2*P of them were ~half of this
+        // kernel's instructions); the tap order of a transposed plan is a sign and a constant
+        const int sgn = a.transposed ? -1 : 1, t00 = a.transposed ? a.Krow - 1 - a.k0 : a.k0;
+        const unsigned b0 = has0 ? o0 + (unsigned)((t00 + sgn * tseq) * 4) : 0x80000000u;
+        const unsigned b1 = has1 ? o1 + (unsigned)((t00 + sgn * tseq) * 4) : 0x80000000u;
+        const int step = sgn * G::N2 * 4;
 #pragma unroll
-    for (int n1 = 0; n1 < P; ++n1) {
-      const int n = G::N2 * n1 + tseq;
-      const int tap = n / a.dil;
-      const bool hit = (tap * a.dil == n) && tap < a.K;
-      const int ts = a.transposed ? a.Krow - 1 - (a.k0 + tap) : a.k0 + tap;
-      v[n1].x = (hit && has0) ? w0[ts] : 0.f;
-      v[n1].y = (hit && has1) ? w1[ts] : 0.f;
+        for (int n1 = 0; n1 < P; ++n1) {
+          const bool hit = G::N2 * n1 + tseq < a.K;
+          v[n1].x = buf_load_f32(wr, hit ? b0 + (unsigned)(step * n1) : 0x80000000u, 0);
+          v[n1].y = buf_load_f32(wr, hit ? b1 + (unsigned)(step * n1) : 0x80000000u, 0);
+        }
+      } else {
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int n = G::N2 * n1 + tseq;
+          const int tap = n / a.dil;
+          const bool hit = (tap * a.dil == n) && tap < a.K;
+          const int ts = a.transposed ? a.Krow - 1 - (a.k0 + tap) : a.k0 + tap;
+          v[n1].x = buf_load_f32(wr, (hit && has0) ? o0 + (unsigned)ts * 4u : 0x80000000u, 0);
+          v[n1].y = buf_load_f32(wr, (hit && has1) ? o1 + (unsigned)ts * 4u : 0x80000000u, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int n = G::N2 * n1 + tseq;
+        const int tap = n / a.dil;
+        const bool hit = (tap * a.dil == n) && tap < a.K;
+        const int ts = a.transposed ? a.Krow - 1 - (a.k0 + tap) : a.k0 + tap;
+        v[n1].x = (hit && has0) ? w0[ts] : 0.f;
+        v[n1].y = (hit && has1) ? w1[ts] : 0.f;
+      }
     }
     passA_fft_twiddle_store<G, -1>(v, z, tseq, twA);
   }

@@ -32,6 +32,10 @@ struct WGradArgs {
   int n_items, items_per_slice;    // (b, tile) items in all / per slice (a multiple of NB)
   int nob, nib;                    // 4-channel blocks per group: outputs, inputs
   float scale;                     // 1 / (4 T)
+  long long part_stride;           // floats between two slices of `part` (>= Cout*Cig*Krow)
+  float* dbpart;                   // optional: bias gradient partials, dbpart[slice*part_stride + channel] (dense kernel,
+                                   // first tap segment only): db[o] = sum of dY = bin 0 of the gradient spectra this
+                                   // kernel forms anyway -- the separate reduction over dY (a 33 MB read at cfgA) goes away
 };
 
 // acc += conj(y) * x
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
   copy_table_to_lds<TWN, NT>(twl, a.twA, tid);
 
   f2 acc[BP][4][4];                          // [bin pair][o][i]
+  float dbacc[4] = {0.f, 0.f, 0.f, 0.f};     // (thread 0 only: the owner of bin 0)
 #pragma unroll
   for (int m = 0; m < BP; ++m)
 #pragma unroll
@@ -185,6 +190,8 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
             for (int o = 0; o < 4; ++o)
 #pragma unroll
               for (int i = 0; i < 4; ++i) acc[m][o][i] = pkfma(y2[o], x2[i], acc[m][o][i]);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) dbacc[o] += y2[o].x;     // 2 * (sum of this tile's gradient samples)
           }
         }
       }
@@ -194,6 +201,11 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
 
   // -------------------------------------------------- inverse: 16 cross-spectra = 8 packed sequences, NSEQ at a time
   const int ci_base = g * a.Cig + ib * 4, co_base = g * a.Cog + ob * 4;
+  if (a.dbpart != nullptr && ib == 0 && tid == 0) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      if (ob * 4 + o < a.Cog) a.dbpart[(size_t)slice * a.part_stride + co_base + o] = 0.5f * dbacc[o];
+  }
   constexpr int ROUNDS = (8 + NSEQ - 1) / NSEQ;
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
       const int o = pk >> 1, ip = pk & 1;
       const int co = ob * 4 + o, ci = ib * 4 + 2 * ip;
       if (co < a.Cog) {
-        float* out0 = a.part + (((size_t)slice * a.Cout + (co_base + o)) * a.Cig + ci) * a.Krow + a.tap0;
+        float* out0 = a.part + (size_t)slice * a.part_stride + (((size_t)(co_base + o)) * a.Cig + ci) * a.Krow + a.tap0;
         float* out1 = out0 + a.Krow;
         const int nbase = (tseq >> G::LGS) + P * P * j;
         const int kd = (a.K - 1) * a.dil + 1;
@@ -406,7 +418,7 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_diag_kernel(const WGradArgs a) 
     seq_sync<G>();
     passB_load<G>(v, zseq, tseq);
     const int j = passB_compute<G, +1>(v, tseq, twB);
-    float* out0 = a.part + ((size_t)slice * a.Cout + c0) * a.Krow + a.tap0;
+    float* out0 = a.part + (size_t)slice * a.part_stride + (size_t)c0 * a.Krow + a.tap0;
     float* out1 = out0 + a.Krow;
     const int nbase = (tseq >> G::LGS) + P * P * j;
     const int kd = (a.K - 1) * a.dil + 1;

@@ -222,7 +222,9 @@ def _fft_conv_impl(signal, kernel, bias, stride, padding, dilation, groups, padd
         pads, drop = _string_padding(padding, kernel, stride, dilation, n)
         out = _fft_conv_impl(signal, kernel, bias, stride, pads, dilation, groups, padding_mode, spectrum, plan)
         if any(drop):
-            out = out[(slice(None), slice(None)) + tuple(slice(d, None) for d in drop)]
+            # (a fresh contiguous tensor, as documented and as torch's convolutions return: a view would pin the
+            # larger buffer and break downstream .view() calls)
+            out = out[(slice(None), slice(None)) + tuple(slice(d, None) for d in drop)].contiguous()
         return out
     if signal.dtype in _LOW_PRECISION and kernel.dtype == signal.dtype and (bias is None or bias.dtype == signal.dtype):
         # half-precision tensors in, half-precision tensor out; the arithmetic is the fp32 path (one cast pass each way)
@@ -265,6 +267,11 @@ def fft_conv_transpose(
 def _fft_conv_transpose_impl(signal, kernel, bias, stride, padding, output_padding, dilation, groups, spectrum,
                              plan=None):
     """Shared by the functional and the transposed modules (``spectrum`` / ``plan``: see ``_fft_conv_impl``)."""
+    if signal.dtype in _LOW_PRECISION and kernel.dtype == signal.dtype and (bias is None or bias.dtype == signal.dtype):
+        # half-precision tensors: fp32 arithmetic, one cast pass each way (as the forward op)
+        out = _fft_conv_transpose_impl(signal.float(), kernel.float(), None if bias is None else bias.float(), stride,
+                                       padding, output_padding, dilation, groups, None, None)
+        return out.to(signal.dtype)
     if _needs_grad(signal, kernel, bias):
         from .autograd import FFTConvTransposeFunction     # differentiable like the reference's op graph
         n = signal.ndim - 2

@@ -50,6 +50,28 @@ class _SpectrumCache:
             self.__dict__["_spectrum_cache"] = cached
         return cached[1]
 
+    # The cached spectrum and the remembered plan hold native handles (ctypes pointers, a loaded library): they are
+    # per-process acceleration state, not part of the module.  copy.deepcopy (EMA / AveragedModel, quantization flows),
+    # pickle and torch.save(module) therefore see the module WITHOUT them -- exactly what a reference FFTConv module,
+    # a plain nn.Conv subclass, carries -- and the copy rebuilds its own on first use.
+    _TRANSIENT = ("_spectrum_cache", "_last_plan")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for key in self._TRANSIENT:
+            state.pop(key, None)
+        return state
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        clone = cls.__new__(cls)
+        memo[id(self)] = clone
+        for key, value in self.__dict__.items():
+            if key not in self._TRANSIENT:
+                clone.__dict__[key] = copy.deepcopy(value, memo)
+        return clone
+
     def _apply(self, fn, *args, **kwargs):       # .to() / .cuda() / .float(): new storage, new spectrum
         self.invalidate_kernel_spectrum()
         self.__dict__.pop("_last_plan", None)
@@ -90,6 +112,9 @@ class _FFTConvTransposeForward(_SpectrumCache, nn.Module):
 
     def forward(self, signal: Tensor):
         assert signal.ndim == self.weight.ndim
+        if signal.dtype in F_._LOW_PRECISION:      # half-precision tensors: the functional casts (fp32 arithmetic)
+            return F_._fft_conv_transpose_impl(signal, self.weight, self.bias, self.stride, self.padding,
+                                               self.output_padding, self.dilation, self.groups, None, None)
         plan = F_._plan_for(signal, self.weight, self.bias, self.stride, self.padding, self.dilation,
                             self.groups, "constant", transposed=True, output_padding=self.output_padding)
         return F_._fft_conv_transpose_impl(signal, self.weight, self.bias, self.stride, self.padding,

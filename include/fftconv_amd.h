@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 4
+#define FC_ABI_VERSION 5
 
 enum fc_status {
   FC_OK = 0,
@@ -124,6 +124,14 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
  * same device -- the caller needs its answer to size `partial` anyway). */
 int fc_wgrad1d_slices(const fc_desc* desc);
 int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* partial, int slices, void* hip_stream);
+/* The same launch with the bias gradient folded in (ABI 5): db[o] = sum over batch and row of dY[b][o][t] is bin 0 of the
+ * gradient spectra the kernel forms anyway, so the separate reduction over dY (tests/test_functional.py:114-117 pins db)
+ * costs nothing.  Slice s of the result starts at partial + s*slice_stride floats (0 = densely packed) and at
+ * db_partial + s*slice_stride: one buffer of `slices` rows [dW | db] with db_partial = partial + Cout*Cin/groups*K is
+ * summed by ONE reduction.  db_partial may be NULL.  Not available for depthwise plans (fc_wgrad1d_db_supported = 0). */
+int fc_wgrad1d_db_supported(const fc_desc* desc);
+int fc_wgrad1d_db(const fc_desc* desc, const float* x, const float* dy, float* partial, float* db_partial,
+                  long long slice_stride, int slices, void* hip_stream);
 
 /* Profiling variant of fc_forward (not part of the drop-in surface; the plan stays immutable):
  * `stamps` is a device buffer of 16 * fc_debug_grid(plan) uint64 in which lane 0 of the waves of the

@@ -105,3 +105,42 @@ def test_spectrum_broadcast_needs_agreeing_plan_signatures_world2_gloo():
         mp.spawn(_sig_worker, args=(world, _free_port(), out), nprocs=world, join=True)
         assert out[0] == ((1, 1.0), (1, 1.0), (1, 1.0))
         assert out[1] == ((0, 1.0), (1, 2.0), (1, 2.0))     # received once, then two local transforms
+
+
+# ---- strong scaling as bench.py --scaling strong does it: the node-level batch of a BASELINE.json problem is split over
+# the ranks; the whole-problem throughput is (outputs of ALL ranks) / (max over ranks of the time)
+def _strong_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import importlib.util
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        res = {}
+        for name, total in bench.STRONG_BATCH.items():
+            lo, hi = shard_range(total, world, rank)
+            mine = torch.zeros(total, dtype=torch.int64)
+            mine[lo:hi] = 1                       # batch items this rank convolves
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            # per-item outputs x the whole batch, over the slowest rank's time: what `value` is made of
+            per_item, t_rank = 1000, torch.tensor([0.5 * (hi - lo)], dtype=torch.float64)
+            dist.all_reduce(t_rank, op=dist.ReduceOp.MAX)
+            res[name] = (bool((mine == 1).all()), hi - lo, per_item * total / float(t_rank))
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_strong_scaling_split_world2_gloo():
+    world = 2
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_strong_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+        assert len(out) == world
+        for name in ("cfgA", "cfgB", "cfgC", "cfgD"):
+            covered0, n0, v0 = out[0][name]
+            covered1, n1, v1 = out[1][name]
+            assert covered0 and covered1, "every batch item convolved exactly once"
+            assert abs(n0 - n1) <= 1 and v0 == v1          # balanced shards, one agreed throughput figure

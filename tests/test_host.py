@@ -222,3 +222,40 @@ def test_transposed_ops_route_through_autograd_when_grad_is_needed(monkeypatch):
     assert hit["args"][3:8] == ((2,), (0,), (1,), (1,), 1)
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         F_.fft_conv_transpose(x, w)          # without grad it takes the plain (device) path
+
+
+def test_modules_copy_and_pickle_without_their_native_handles():
+    """A module that has run carries a cached kernel spectrum and its last plan (ctypes handles) in __dict__; deepcopy
+    (EMA / AveragedModel, quantization flows), pickle and torch.save(module) must see a plain nn.Conv subclass, as the
+    reference's FFTConv modules are."""
+    import copy
+    import io
+    import pickle
+
+    import fft_conv_pytorch_amd as pkg
+
+    class FakeHandle:                       # stands in for a _native.Plan / KernelSpectrum: refuses both protocols
+        def __reduce__(self):
+            raise ValueError("ctypes objects containing pointers cannot be pickled")
+
+        def __deepcopy__(self, memo):
+            raise ValueError("ctypes objects containing pointers cannot be pickled")
+
+    for cls, args in ((pkg.FFTConv2d, (4, 6, 3)), (pkg.FFTConvTranspose1d, (4, 6, 3))):
+        layer = cls(*args)
+        layer.__dict__["_spectrum_cache"] = (("tag",), FakeHandle())
+        layer.__dict__["_last_plan"] = (("sig",), FakeHandle())
+        twin = copy.deepcopy(layer)
+        assert "_spectrum_cache" not in twin.__dict__ and "_last_plan" not in twin.__dict__
+        assert torch.equal(twin.weight, layer.weight) and twin.weight is not layer.weight
+        assert "_spectrum_cache" in layer.__dict__          # the original keeps its cache
+        back = pickle.loads(pickle.dumps(layer))
+        assert torch.equal(back.weight, layer.weight) and "_last_plan" not in back.__dict__
+        buf = io.BytesIO()
+        torch.save(layer, buf)
+        buf.seek(0)
+        again = torch.load(buf, weights_only=False)
+        assert torch.equal(again.bias, layer.bias)
+        # inside a container, as model-averaging utilities copy whole models
+        model = torch.nn.Sequential(layer, torch.nn.ReLU())
+        assert torch.equal(copy.deepcopy(model)[0].weight, layer.weight)

@@ -127,8 +127,14 @@ def _grad_weight_plans(x: Tensor, grad: Tensor, wshape, stride, padding, dilatio
     # signal' (Cig, [g, b], *S), kernel' ([g, o], b, *Lout), groups' = g
     xt = x.reshape((b, g, cig) + sp).permute((2, 1, 0) + tuple(range(3, 3 + n))).reshape((cig, g * b) + sp).contiguous()
     gt = grad.reshape((b, g, cog) + lo).permute((1, 2, 0) + tuple(range(3, 3 + n))).reshape((g * cog, b) + lo).contiguous()
-    out = F_.fft_conv(xt, gt, None, stride=dilation, padding=padding, dilation=stride, groups=g,
-                      padding_mode=padding_mode)                    # (Cig, g*Cog, >= k per axis)
+    key = ("dwp", tuple(xt.shape), tuple(gt.shape), stride, padding, dilation, g, padding_mode, xt.device, xt.dtype)
+    plan = _BWD_PLANS.get(key)
+    if plan is None:
+        plan = F_._plan_for(xt, gt, None, dilation, padding, stride, g, padding_mode)
+        if len(_BWD_PLANS) > 256:
+            _BWD_PLANS.clear()
+        _BWD_PLANS[key] = plan
+    out = F_._forward_native(xt, F_.transform_kernel(plan, gt), None)      # (Cig, g*Cog, >= k per axis)
     index = (slice(None), slice(None)) + tuple(slice(0, k) for k in ksize)
     return out[index].transpose(0, 1).contiguous()                  # (g*Cog, Cig, *k)
 

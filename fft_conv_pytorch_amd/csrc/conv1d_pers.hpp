@@ -49,10 +49,16 @@ __device__ __forceinline__ void stamp_clock(unsigned long long* buf, int item, i
 // STAMPS: the profiling hook (fc_forward_stamped) is a build of its own -- compiled into the product kernel, even
 // switched off, its guarded stores made hipcc put a full s_waitcnt vmcnt(0) between the two items of a workgroup
 // (a pending store's registers are reused), i.e. a wait for every output store of the first item.
+// PH4 (with PHASES, a multiple of four phases, 8 -> 8 channel blocks, four slots): the packing is turned round -- a complex
+// sequence carries two PHASES of ONE channel, a wave owns one channel and its two halves the phase pairs (0,1) and (2,3) --
+// so a lane loads / stores all four phases of a position as 16 contiguous bytes (full cache lines per wave-instruction, where
+// PH2's 8 bytes at a 16-byte pitch cost partial-line write-backs and re-fetches: 1.6x the output bytes written at cfgD).
+// The mix contracts the same 8 x 8 matrix per bin; its slots are phases and its steps single output channels.
 template <int P, int S, int CIB, int NB, int NT, bool PHASES = false, int RING = 2, bool DIAG = false, bool SEG = false, bool PH2 = false,
-          bool STAMPS = false>
+          bool STAMPS = false, bool PH4 = false>
 __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs pa) {
   static_assert(!PH2 || (PHASES && !DIAG && !SEG && S == 1 && CIB == 8), "paired phases: plain phase build on a P*P tile");
+  static_assert(!PH4 || (PHASES && !DIAG && !SEG && !PH2 && S == 1 && CIB == 8 && NB == 4), "phase quads: 8 channels x 2 phase pairs");
   using G = Geo<P, S>;
   constexpr int T = G::T;
   constexpr int NPI = CIB / 2;
@@ -76,11 +82,12 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   // batch slot and channel pair of this thread's sequence: slot wave-uniform, except with PH2 where the two halves of
   // a wave are slots 2j and 2j+1 (even / odd phase) of pair wave % 4
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nb = PH2 ? 2 * (wv / NPI) + ((tid >> 5) & 1) : __builtin_amdgcn_readfirstlane(tid / (NPI * G::TS));
-  const int pr = PH2 ? wv % NPI : sq % NPI;
+  // (PH4: nb = phase pair of this half-wave, pr = the wave's channel, sequence (pair, channel) at pair * 8 + channel)
+  const int nb = PH4 ? ((tid >> 5) & 1) : (PH2 ? 2 * (wv / NPI) + ((tid >> 5) & 1) : __builtin_amdgcn_readfirstlane(tid / (NPI * G::TS)));
+  const int pr = PH4 ? wv : (PH2 ? wv % NPI : sq % NPI);
   f2* twl = lds;
   f2* zbuf = lds + TWN;                     // [NSEQ][LSEQ], sequence (slot, pair) at slot * NPI + pair
-  f2* zseq = zbuf + (nb * NPI + pr) * G::LSEQ;
+  f2* zseq = PH4 ? zbuf + (nb * 8 + pr) * G::LSEQ : zbuf + (nb * NPI + pr) * G::LSEQ;
 
   const PadMap pm = make_padmap(a.pad_mode, a.L);
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
@@ -108,6 +115,35 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     const bool has1 = act_in && ci0 + 1 < a.Cig && (!DIAG || g * CIB + ci0 + 1 < a.Cin);
     const unsigned ro0 = ((unsigned)(b - bfirst) * (unsigned)a.Cin + (unsigned)ci0) * (unsigned)a.L * 4u;
     const unsigned ro1 = ro0 + (unsigned)a.L * 4u;
+    if constexpr (PH4) {
+      // wave = channel pr of batch item bA, phases phA .. phA + 3 (phA a multiple of 4: items hold four slots)
+      const int bA = wi.b0 / nph, phA = wi.b0 - bA * nph;
+      const int posA = wi.tile * a.V * nph + phA - a.pad;
+      const bool all_in = (posA >= 0) && (posA + 3 + (T - 1) * nph < a.L);
+      const bool chan = pr < a.Cig;
+      const unsigned rA = ((unsigned)(bA - bfirst) * (unsigned)a.Cin + (unsigned)pr) * (unsigned)a.L * 4u;
+      // 16-byte accesses need the row base and the tile position on 16-byte boundaries (uniform test; else 4-byte loads)
+      const bool al16 = (((size_t)xbase | ((size_t)a.L * 4) | ((size_t)(unsigned)posA * 4)) & 15) == 0;
+      if (all_in && al16) {
+        const unsigned q0 = chan ? rA + (unsigned)(posA + (tid & 63) * nph) * 4u : 0x80000000u;
+        const unsigned step4 = 256u * (unsigned)nph;
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) {
+          const f4 q = buf_load_f32x4(xg, q0, step4 * m);
+          v[2 * m] = q.xy; v[2 * m + 1] = q.zw;
+        }
+        return;        // (the halves are traded in fetch_finish)
+      }
+      // border tiles / unaligned rows: per-sample padded loads of this half-wave's two phases
+      const unsigned ro = ((unsigned)(bA - bfirst) * (unsigned)a.Cin + (unsigned)pr) * (unsigned)a.L * 4u;
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) {
+        const int pos = posA + 2 * nb + (G::N2 * n1 + tseq) * nph;
+        v[n1].x = buf_load_f32(xg, padded_offset(ro, pos, a.L, a.pad, pm, chan), 0);
+        v[n1].y = buf_load_f32(xg, padded_offset(ro, pos + 1, a.L, a.pad, pm, chan), 0);
+      }
+      return;
+    }
     if constexpr (PH2) {
       // even slot of this wave (wave-uniform), its batch item and (even) phase; the odd slot is the next phase
       const int vbA = wi.b0 + 2 * (wv / NPI), bA = vbA / nph, phA = vbA - bA * nph;
@@ -156,6 +192,19 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   // second half of a paired-phase fetch, run when the item starts (its loads have long landed): the partner lanes trade
   // the halves they loaded for each other.  Recomputes which path fetch() took for this item.
   auto fetch_finish = [&](const WorkItem& wi, f2 (&v)[P]) {
+    if constexpr (PH4) {
+      // lanes 0-31 keep (phase 0, 1) of the positions both lane groups loaded, lanes 32-63 get (phase 2, 3)
+      const int bA = wi.b0 / nph, phA = wi.b0 - bA * nph;
+      const int posA = wi.tile * a.V * nph + phA - a.pad;
+      const int bfirst = wi.b0 / nph;
+      const float* xbase = a.x + ((size_t)bfirst * a.Cin + (size_t)(wi.goc / a.n_ochunks) * a.Cig) * a.L;
+      const bool all_in = (posA >= 0) && (posA + 3 + (T - 1) * nph < a.L);
+      const bool al16 = (((size_t)xbase | ((size_t)a.L * 4) | ((size_t)(unsigned)posA * 4)) & 15) == 0;
+      if (all_in && al16) {
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) { swap_halves_c<0>(v[2 * m], v[2 * m + 1]); swap_halves_c<1>(v[2 * m], v[2 * m + 1]); }
+      }
+    }
     if constexpr (PH2) {
       const bool has1 = nb < wi.nbc && 2 * pr + 1 < a.Cig;
       const int vbA = wi.b0 + 2 * (wv / NPI), bA = vbA / nph, phA = vbA - bA * nph;
@@ -171,14 +220,14 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
   // ---- one item: forward FFT, mix, [request the next item's samples], inverse FFT, store
   auto run = [&](const WorkItem& wi, int it, f2 (&v)[P], bool more, const WorkItem& wnext, f2 (&vnext)[P]) {
     const int g = wi.goc / a.n_ochunks, oc = wi.goc % a.n_ochunks;
-    const bool act_in = nb < wi.nbc;
+    const bool act_in = PH4 ? true : nb < wi.nbc;          // (phase quads: every item holds its four slots)
     // DIAG (depthwise): the spectrum is [channel pair][T/2] float4 = {H(2p)[f], H(2p+1)[f]}, 8 channels per block g
     const BufRsrc wg = DIAG ? make_rsrc(a.wspec + (size_t)g * NPI * (T / 2), (unsigned)(NPI * (T / 2) * 16))
                             : make_rsrc(a.wspec + (size_t)g * wgroup, (unsigned)(wgroup * 16));
     stampi(it, 0);
     stampc(it, 12);
     // bias of this lane's two output channels, requested now and used in the last pass
-    const int cg0 = g * a.Cog + oc * a.cob + 2 * pr;
+    const int cg0 = g * a.Cog + oc * a.cob + (PH4 ? pr : 2 * pr);     // (PH4: one output channel per wave)
     const bool ok0 = !DIAG || cg0 < a.Cout, ok1 = !DIAG || cg0 + 1 < a.Cout;
     // (buffer loads: a missing bias is an empty resource, a missing channel an offset outside it -- no branch, so
     // nothing waits for these two values here; they are pinned as arrived after the mix, see below)
@@ -256,6 +305,92 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         const f2 z = *zp;
         *zp = mk2(2.f * z.x * ((tid & 1) ? sdw.y : sdw.x), 2.f * z.y * ((tid & 1) ? sdw.w : sdw.z));
       }
+    } else if constexpr (PH4) {
+    // ------------------------------------------------ mix, phase quads: slots are the four phases, sequence (pair hp, channel c)
+    // holds phases 2hp (re) and 2hp+1 (im) of channel c; a step is one output channel (its 8 inputs = 4 float4)
+    const unsigned ostride = (unsigned)(a.Cig_pad / 2) * (T / 2) * 16u;
+    const unsigned wbase = (unsigned)(oc * a.cob) * ostride;
+    constexpr int R4 = 4;
+    static_assert(BP == 1, "one bin pair per thread");
+    const int sb_s = tid / (2 * CIB), sb_o = (tid >> 1) % CIB, sb_f = (tid & 1) ? T / 2 : 0;     // (phase, output, bin) of wave 0
+    const bool sb_act = tid < 4 * CIB * 2;
+    f4 sbw[NPI];
+    if (sb_act) {
+#pragma unroll
+      for (int p = 0; p < NPI; ++p) sbw[p] = buf_load_f32x4(wg, (unsigned)sb_o * ostride, wbase + p * (T / 2) * 16);
+    }
+    f4 w4[R4][NPI];
+    auto issue4 = [&](auto oc_) {
+      constexpr int o = decltype(oc_)::value;
+#pragma unroll
+      for (int p = 0; p < NPI; ++p) w4[o % R4][p] = buf_load_f32x4(wg, (unsigned)tid * 16u, wbase + (unsigned)o * ostride + p * (T / 2) * 16);
+    };
+    static_for<0, R4>([&](auto oc_) { issue4(oc_); });
+    stampi(it, 4);
+    __syncthreads();
+    stampi(it, 5);
+    {
+      float sbv[CIB];
+      if (sb_act) {
+#pragma unroll
+        for (int c = 0; c < CIB; ++c) {
+          const f2 z = zbuf[((sb_s >> 1) * 8 + c) * G::LSEQ + G::nat(sb_f)];
+          sbv[c] = (sb_s & 1) ? z.y : z.x;
+        }
+      }
+      const int f = tid, fm = (T - f) & (T - 1);
+      f2 xe[2][CIB], xo[2][CIB];          // 2 * X of phase 2hp / 2hp+1 of every channel at bin f
+      {
+        const unsigned af = lds_off(zbuf + G::nat(f)), ag = lds_off(zbuf + G::nat(fm));
+        static_for<0, 2>([&](auto hc) {
+          constexpr int hp = decltype(hc)::value;
+          static_for<0, CIB>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            xe[hp][c] = lds_rd_far<(hp * 8 + c) * G::LSEQ * 8>(af);
+            xo[hp][c] = lds_rd_far<(hp * 8 + c) * G::LSEQ * 8>(ag);
+          });
+        });
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) { lds_arrive(xe[hp]); lds_arrive(xo[hp]); }
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp)
+#pragma unroll
+          for (int c = 0; c < CIB; ++c) {
+            const f2 zf = xe[hp][c], zg = xo[hp][c];
+            xe[hp][c] = add_conj(zf, zg);
+            xo[hp][c] = sub_conj_divi(zf, zg);
+          }
+      }
+      static_for<0, CIB>([&](auto oc_) {
+        constexpr int o = decltype(oc_)::value;
+        const f4 (&wc)[NPI] = w4[o % R4];
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+          f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
+#pragma unroll
+          for (int p = 0; p < NPI; ++p) {
+            cmac(ya, xe[hp][2 * p], wc[p].xy); cmac(yb, xo[hp][2 * p], wc[p].xy);
+            cmac(ya, xe[hp][2 * p + 1], wc[p].zw); cmac(yb, xo[hp][2 * p + 1], wc[p].zw);
+          }
+          if (f != 0) {
+            f2* zb = zbuf + (hp * 8 + o) * G::LSEQ;
+            zb[G::nat(f)] = add_pi(ya, yb);
+            zb[G::nat(fm)] = conj_add_iconj(ya, yb);
+          }
+        }
+        if constexpr (o + R4 < CIB) issue4(std::integral_constant<int, o + R4>{});
+      });
+      if (sb_act) {
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < NPI; ++p) {
+          acc = fmaf(2.f * sbv[2 * p], (tid & 1) ? sbw[p].y : sbw[p].x, acc);
+          acc = fmaf(2.f * sbv[2 * p + 1], (tid & 1) ? sbw[p].w : sbw[p].z, acc);
+        }
+        float* dstf = reinterpret_cast<float*>(zbuf + ((sb_s >> 1) * 8 + sb_o) * G::LSEQ + G::nat(sb_f)) + (sb_s & 1);
+        *dstf = acc;
+      }
+    }
     } else {
     // ------------------------------------------------ mix
     // The first two spectrum sets (and the self-paired bins' weights) do not depend on this item's
@@ -447,6 +582,44 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
         for (int k = 0; k < P; ++k)
           if (nbase + P * k < limit) { y0[P * k] = v[k].x + bias0; y1[P * k] = v[k].y + bias1; }
+      } else if constexpr (PH4) {
+        // all four phases of a position leave as 16 bytes: after the trade lane L of the wave holds (phases 0, 1) in
+        // row 2m and (phases 2, 3) in row 2m + 1 of sample 64 m + L.  Phases past the end of the row are shorter by one.
+        const int bA = wi.b0 / nph, phA = wi.b0 - bA * nph;
+        int lim[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lim[j] = min(a.V, (a.Lfull - (phA + j) + nph - 1) / nph - t0);
+        const BufRsrc yr = make_rsrc(a.y + ((size_t)bA * a.Cout + (size_t)(g * a.Cog + oc * a.cob)) * a.Lout, (unsigned)((size_t)a.cob * a.Lout * 4));
+        const int L64 = tid & 63;
+        const unsigned w0 = (unsigned)(((size_t)pr * a.Lout + (size_t)(t0 + L64) * nph + phA) * 4);
+        const unsigned step4 = 256u * (unsigned)nph;
+        const bool al16 = (((size_t)a.y | ((size_t)a.Lout * 4)) & 15) == 0;
+        const int mfull = (al16 && lim[3] >= 64) ? (lim[3] - 64) / 64 + 1 : 0;       // rows m below it: every lane, every phase valid
+#pragma unroll
+        for (int m = 0; m < P / 2; ++m) { swap_halves_c<0>(v[2 * m], v[2 * m + 1]); swap_halves_c<1>(v[2 * m], v[2 * m + 1]); }
+        static_for<0, P / 8>([&](auto bc) {
+          constexpr int m0 = 4 * decltype(bc)::value;
+          if (mfull >= m0 + 4) {
+            static_for<m0, m0 + 4>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              u32x4 d;
+              d.x = __float_as_uint(v[2 * m].x + bias0); d.y = __float_as_uint(v[2 * m].y + bias0);
+              d.z = __float_as_uint(v[2 * m + 1].x + bias0); d.w = __float_as_uint(v[2 * m + 1].y + bias0);
+              __builtin_amdgcn_raw_buffer_store_b128(d, yr, w0, step4 * m, 0);
+            });
+          } else if (64 * m0 < lim[0]) {
+            static_for<m0, m0 + 4>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              if (64 * m < lim[0]) {
+                const int n = 64 * m + L64;
+                buf_store_f32(v[2 * m].x + bias0, yr, w0 | (n < lim[0] ? 0u : 0x80000000u), step4 * m);
+                buf_store_f32(v[2 * m].y + bias0, yr, (w0 + 4u) | (n < lim[1] ? 0u : 0x80000000u), step4 * m);
+                buf_store_f32(v[2 * m + 1].x + bias0, yr, (w0 + 8u) | (n < lim[2] ? 0u : 0x80000000u), step4 * m);
+                buf_store_f32(v[2 * m + 1].y + bias0, yr, (w0 + 12u) | (n < lim[3] ? 0u : 0x80000000u), step4 * m);
+              }
+            });
+          }
+        });
       } else if constexpr (PH2) {
         // both phases of a position leave as 8 bytes: rows 2m and 2m + 1 trade halves so that lane L holds (even
         // phase, odd phase) of sample 64 m + L.  The odd phase may be one sample shorter at the very end of a row.

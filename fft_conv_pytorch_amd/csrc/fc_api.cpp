@@ -530,7 +530,14 @@ static int plan_1d_persistent(fc_plan* p) {
     for (int goc = 0; goc < p->n_ochunks * p->G; ++goc)
       for (int c = 0; c < nfull; ++c) items.push_back({c * nb, nb, tile, goc});
   }
-  if (nb >= 2 && (int64_t)items.size() > slots) {
+  // phase quads (conv1d_pers.hpp PH4): four phases, a multiple of 4 of them per batch item, one full 8 x 8 channel block;
+  // FFTCONV_PH2 = 0 / 1 keeps single phases / pairs (A/B runs, tests).  Decided before the tail split: a quad item cannot
+  // be halved (a wave owns all four phases of its channel).
+  const char* ph_env = getenv("FFTCONV_PH2");
+  const int ph_want = ph_env ? atoi(ph_env) : 2;
+  const bool ph_base = p->ph > 1 && !p->slot_tiles && !p->diag && !p->wide && p->nseg == 1 && nb >= 2 && t->S == 1;
+  const bool quads = ph_want >= 2 && ph_base && p->ph % 4 == 0 && nb == 4 && p->Cig == 8 && p->cob == 8 && p->Cog % 8 == 0 && !p->bd_gs;
+  if (nb >= 2 && (int64_t)items.size() > slots && !quads) {
     const int64_t tail = (int64_t)items.size() % slots;
     if (tail > 0 && tail <= slots / 2) {
       std::vector<fc::WorkItem> split;
@@ -557,13 +564,9 @@ static int plan_1d_persistent(fc_plan* p) {
   FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
   FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;
-  {
-    // phases in pairs: an even number of phases, slots = batch items (so slots 2j, 2j+1 are neighbouring phases of one
-    // batch item), plain dense-block kernel on a P*P tile; FFTCONV_PH2=0 keeps the 4-byte accesses (A/B runs, tests)
-    const char* env = getenv("FFTCONV_PH2");
-    p->ph2 = (!env || atoi(env) != 0) && p->ph > 1 && p->ph % 2 == 0 && !p->slot_tiles && !p->diag && !p->wide && p->nseg == 1 &&
-             nb >= 2 && t->S == 1;
-  }
+  // phases in pairs: an even number of phases, slots = batch items (so slots 2j, 2j+1 are neighbouring phases of one
+  // batch item), plain dense-block kernel on a P*P tile; quads (above) take precedence
+  p->ph2 = quads ? 2 : ((ph_want != 0 && ph_base && p->ph % 2 == 0) ? 1 : 0);
   return FC_OK;
 }
 
@@ -1000,7 +1003,9 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   fc::f2* wsB = wsA + p.ws_a;
   const int nd = p.nd;
   const int Co = (int)p.d.out_channels;
-  FC_HIP(hipMemsetAsync(w_hat, 0, p.spectrum_bytes, st));    // phantom channels stay zero
+  // phantom channels (padding of the channel counts up to the chunk size) must read as zero; without any, every
+  // entry of the spectrum is written by the passes below and the fill (6 us per call on a 2-D training step) is skipped
+  if (p.Cig_pad != p.Cig || p.nd_Cog_pad != p.Cog) FC_HIP(hipMemsetAsync(w_hat, 0, p.spectrum_bytes, st));
   fc::RowsR2CArgs r{};
   r.src = weight; r.dst = wsA; r.twA = p.twx.twA; r.twB = p.twx.twB; r.from_kernel = 1;
   r.kx = (int)p.d.kernel[nd - 1]; r.dx = (int)p.d.dilation[nd - 1];

@@ -186,11 +186,11 @@ constexpr size_t pers_lds_bytes(int nb) { return ((size_t)FC_P * GG::N2 + (size_
 
 // batch-sharing kernel builds: PHASES (dilation as phases) x DIAG (depthwise blocks); the plain one keeps its
 // immediate offsets and is the only one the headline configuration runs
-template <int NB, bool PHASES, bool DIAG, bool SEG = false, bool PH2 = false, bool STAMPS = false>
+template <int NB, bool PHASES, bool DIAG, bool SEG = false, bool PH2 = false, bool STAMPS = false, bool PH4 = false>
 hipError_t launch_pers_variant(const Conv1dPersArgs& a, int grid, hipStream_t st) {
   constexpr int NT = NB * 4 * GG::TS;
   const size_t lds = pers_lds_bytes(NB);
-  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PH2, STAMPS>;
+  auto k = conv1d_pers_kernel<FC_P, FC_S, 8, NB, NT, PHASES, 2, DIAG, SEG, PH2, STAMPS, PH4>;
   static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
@@ -209,6 +209,9 @@ hipError_t launch_pers(const Conv1dPersArgs& a, int grid, hipStream_t st) {
     if (ph && dg) return launch_pers_variant<NB, true, true>(a, grid, st);
     const bool stamped = a.c.stamps != nullptr;       // profiling builds exist for the plain and the phase kernels only
 #if FC_S == 1
+    if constexpr (NB == 4) {
+      if (ph && a.c.ph2 == 2 && !stamped) return launch_pers_variant<NB, true, false, false, false, false, true>(a, grid, st);
+    }
     if (ph && a.c.ph2) return stamped ? launch_pers_variant<NB, true, false, false, true, true>(a, grid, st)
                                       : launch_pers_variant<NB, true, false, false, true>(a, grid, st);
 #endif

@@ -523,7 +523,7 @@ def test_paired_dilation_phases_match_single_phases(monkeypatch):
         b = torch.randn(C, generator=gen).to(DEV)
         outs = {}
         for ph2 in ("1", "0"):
-            monkeypatch.setenv("FFTCONV_PH2", ph2)       # (read at plan creation)
+            monkeypatch.setenv("FFTCONV_PH2", ph2)       # (read at plan creation; "1" = pairs even where quads would run)
             _native.clear_plan_cache()
             outs[ph2] = fft_conv(x, w, b, padding=pad, padding_mode=mode, dilation=dil, groups=g)
         xd = x.double()
@@ -534,5 +534,45 @@ def test_paired_dilation_phases_match_single_phases(monkeypatch):
             want = F.conv1d(xd, w.double(), b.double(), padding=pad, dilation=dil, groups=g)
         assert _rel(outs["1"], want) < REL_TOL, (B, C, g, L, k, dil, pad, mode)
         assert _rel(outs["0"], want) < REL_TOL
+    monkeypatch.delenv("FFTCONV_PH2", raising=False)
+    _native.clear_plan_cache()
+
+
+# ----------------------------------------------------------------------------- dilation phases in quads (16-byte accesses)
+def test_dilation_phase_quads_match_pairs_and_torch(monkeypatch):
+    """A dilation that is a multiple of 4 on a full 8 -> 8 channel block runs its phases in QUADS (round 3, conv1d_pers.hpp
+    PH4): a complex sequence carries two phases of one channel, a lane loads / stores all four phases of a position as 16
+    bytes.  Against the pairs build (FFTCONV_PH2=1), the single-phase build (=0) and torch in float64: rows whose length
+    is not a multiple of 4 (the 16-byte path must fall back), odd paddings (unaligned tile positions), phases of unequal
+    length at the row end, every padding mode (border tiles), dilation 8 (two quads per batch item), groups of 8 and
+    batch sizes that leave tail items."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv
+    gen = torch.Generator().manual_seed(404)
+    cases = [  # batch, channels, groups, L, k, dilation, padding, mode
+        (8, 8, 1, 40000, 129, 4, 0, "constant"),         # aligned: the 16-byte path everywhere
+        (8, 8, 1, 40001, 129, 4, 0, "constant"),         # L % 4 != 0: 4-byte fallback on loads and stores
+        (3, 16, 2, 36864, 257, 4, 256, "constant"),      # aligned padding, two groups, odd batch
+        (4, 8, 1, 30002, 65, 4, 31, "reflect"),          # odd padding, border tiles by index map
+        (2, 8, 1, 50000, 33, 8, 64, "circular"),         # dilation 8: two quads per batch item
+        (5, 64, 8, 20480, 100, 4, 6, "replicate"),       # cfgD-like grouping
+        (16, 8, 1, 4099, 17, 4, 4, "constant"),          # short rows, unequal phase lengths
+    ]
+    for B, C, g, L, k, dil, pad, mode in cases:
+        x = torch.randn(B, C, L, generator=gen).to(DEV)
+        w = (torch.randn(C, C // g, k, generator=gen) / math.sqrt(C // g * k)).to(DEV)
+        b = torch.randn(C, generator=gen).to(DEV)
+        outs = {}
+        for knob in ("2", "1", "0"):
+            monkeypatch.setenv("FFTCONV_PH2", knob)
+            _native.clear_plan_cache()
+            outs[knob] = fft_conv(x, w, b, padding=pad, padding_mode=mode, dilation=dil, groups=g)
+        xd = x.double()
+        if mode != "constant" and pad:
+            want = F.conv1d(F.pad(xd, (pad, pad), mode=mode), w.double(), b.double(), dilation=dil, groups=g)
+        else:
+            want = F.conv1d(xd, w.double(), b.double(), padding=pad, dilation=dil, groups=g)
+        for knob in ("2", "1", "0"):
+            assert _rel(outs[knob], want) < REL_TOL, (knob, B, C, g, L, k, dil, pad, mode)
     monkeypatch.delenv("FFTCONV_PH2", raising=False)
     _native.clear_plan_cache()

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "direct_f64.h"
+#include "fft_f64.h"
 #include "fc_internal.h"
 #include "fftconv_amd.h"
 
@@ -38,6 +39,23 @@ int fail(int code, const char* fmt, ...) {
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
     if (e_ != hipSuccess) return fail(FC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// Plan creation allocates and uploads device tables (twiddles, work lists) with synchronous calls: it must run OUTSIDE
+// stream capture -- run the call once before capturing; every later call of the same shape only launches kernels on the
+// caller's stream and is capture-safe (tests/test_gpu_round3.py).  A capture error gets that hint instead of a bare code.
+#define FC_HIP_SETUP(expr)                                                               \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      const char* name_ = hipGetErrorName(e_);                                           \
+      (void)hipGetLastError();                                                           \
+      if (name_ && std::strstr(name_, "Capture"))                                        \
+        return fail(FC_ERR_HIP, "%s: %s -- plans cannot be created while a stream is being captured: run this call once "  \
+                    "before the capture (plan creation allocates device tables; later calls only launch kernels)", #expr, \
+                    hipGetErrorString(e_));                                              \
+      return fail(FC_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));                   \
+    }                                                                                    \
   } while (0)
 
 const fc::TileImpl* const* all_tiles(int* n) {
@@ -84,10 +102,10 @@ int get_twiddles(const fc::TileImpl* t, Twiddles* out) {
       b[(size_t)r * P + k] = fc::f2{(float)std::cos(ang), (float)std::sin(ang)};
     }
   Twiddles tw;
-  FC_HIP(hipMalloc(&tw.twA, a.size() * sizeof(fc::f2)));
-  FC_HIP(hipMalloc(&tw.twB, b.size() * sizeof(fc::f2)));
-  FC_HIP(hipMemcpy(tw.twA, a.data(), a.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
-  FC_HIP(hipMemcpy(tw.twB, b.data(), b.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
+  FC_HIP_SETUP(hipMalloc(&tw.twA, a.size() * sizeof(fc::f2)));
+  FC_HIP_SETUP(hipMalloc(&tw.twB, b.size() * sizeof(fc::f2)));
+  FC_HIP_SETUP(hipMemcpy(tw.twA, a.data(), a.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
+  FC_HIP_SETUP(hipMemcpy(tw.twB, b.data(), b.size() * sizeof(fc::f2), hipMemcpyHostToDevice));
   g_tw[key] = tw;
   *out = tw;
   return FC_OK;
@@ -151,6 +169,7 @@ struct fc_plan {
                               // stride-1 samples per tile, bin columns per plane = nxt * Fx
   int nyt, Vy;                // the same for the middle axis of a 3-D problem (one c2c launch per tile)
   int nd_cob, nd_Cog_pad;
+  int f64_T, f64_V, f64_ntiles, f64_cob;   // float64 1-D FFT path (fft_f64.hip): tile, valid samples, tiles per row, out-chunk; 0 = direct kernel
   int planes;                 // 3-D: plane-major three-launch pipeline (planes3d.hpp) instead of the five separable passes
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
@@ -423,9 +442,18 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
   if (!current_device_cus(&cus)) return fail(FC_ERR_HIP, "cannot query the current device");
   const int64_t per_item_units = (int64_t)p->n_ochunks * p->G;
   // {tile, batch items per workgroup (0 = general kernel), resident workgroups per CU, us per workgroup}
-  struct Cand { int T, nb, wgs_per_cu; double t_item; };
-  const Cand cands[] = {{256, 0, 8, 11.7}, {512, 0, 6, 17.0}, {1024, 0, 4, 25.5}, {2048, 0, 2, 28.9},
-                        {2048, 2, 1, 19.5}, {1024, 2, 2, 16.0}, {1024, 4, 1, 15.0}};
+  // Launch-time model (round 3, `profiles/r03_planner_sweep.jsonl`: every candidate forced in turn on 12 shapes):
+  //   general kernel        est = rounds x t_item, one item per workgroup (t_item: a full round, launch included)
+  //   batch-sharing kernel  workgroups run up to two items back to back (grid as plan_1d_persistent builds it);
+  //                         est = kLaunchUs + sum over waves of workgroups of (items per workgroup x t(occupancy)),
+  //                         t(occ) between t_alone (one workgroup on its CU) and t_item (CU full): a 256-thread
+  //                         workgroup alone on a CU runs an item in 10.5 us, beside a second one in 14.2
+  // The round-2 table priced a batch-sharing workgroup at 15-19.5 us whatever it ran beside and however many items it
+  // took: 15-25 % regret wherever fewer workgroups than slots exist or the grid spills into a second wave.
+  struct Cand { int T, nb, wgs_per_cu; double t_item, t_alone; };
+  const Cand cands[] = {{256, 0, 8, 11.7, 0}, {512, 0, 6, 17.0, 0}, {1024, 0, 4, 25.5, 0}, {2048, 0, 2, 28.9, 0},
+                        {2048, 2, 1, 17.3, 17.3}, {2048, 1, 2, 26.0, 13.4}, {1024, 2, 2, 14.2, 10.5}, {1024, 4, 1, 13.3, 13.3}};
+  const double kLaunchUs = 4.0;
   double best = 0;
   int best_T = 0, best_nb = 0, best_ph = 1;
   bool best_tiles = false;
@@ -451,7 +479,20 @@ static int choose_fast_path(fc_plan* p, int* tile_out) {
       const int64_t groups_of = by_tiles ? B * ((nt + c.nb - 1) / c.nb) : ((B + std::max(c.nb, 1) - 1) / std::max(c.nb, 1)) * nt;
       const int64_t items = groups_of * per_item_units;
       const int64_t slots = (int64_t)cus * c.wgs_per_cu;
-      const double est = (double)((items + slots - 1) / slots) * c.t_item;
+      double est;
+      if (c.nb == 0) {
+        est = (double)((items + slots - 1) / slots) * c.t_item;
+      } else {
+        const int64_t grid = std::max<int64_t>((items + 1) / 2, std::min<int64_t>(items, slots));
+        const double ipw = (double)items / (double)grid;                 // 1 .. 2 items per workgroup
+        auto t_occ = [&](int64_t wgs) {                                  // per item, `wgs` workgroups spread over the CUs
+          const int64_t occ = std::min<int64_t>(c.wgs_per_cu, (wgs + cus - 1) / cus);
+          return c.wgs_per_cu > 1 ? c.t_alone + (c.t_item - c.t_alone) * (double)(occ - 1) / (double)(c.wgs_per_cu - 1) : c.t_item;
+        };
+        const int64_t full = grid / slots, rem = grid % slots;
+        // (the makespan of a wave is its slowest workgroup: whole items)
+        est = kLaunchUs + (double)full * std::ceil(ipw) * c.t_item + (rem ? std::ceil(ipw) * t_occ(rem) : 0.0);
+      }
       if (best_T == 0 || est < best) { best = est; best_T = c.T; best_nb = c.nb; best_ph = ph; best_tiles = by_tiles; }
     }
   }
@@ -561,8 +602,8 @@ static int plan_1d_persistent(fc_plan* p) {
   // up to two items per workgroup (the second one's input is prefetched): item i and i + grid
   p->pers_grid = (int)std::max<int64_t>((p->pers_items + 1) / 2, std::min<int64_t>(p->pers_items, slots));
   if (p->wide) p->pers_grid = p->pers_items;         // one item per workgroup
-  FC_HIP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
-  FC_HIP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
+  FC_HIP_SETUP(hipMalloc(&p->d_items, items.size() * sizeof(fc::WorkItem)));
+  FC_HIP_SETUP(hipMemcpy(p->d_items, items.data(), items.size() * sizeof(fc::WorkItem), hipMemcpyHostToDevice));
   p->pers_nb = nb;
   // phases in pairs: an even number of phases, slots = batch items (so slots 2j, 2j+1 are neighbouring phases of one
   // batch item), plain dense-block kernel on a P*P tile; quads (above) take precedence
@@ -714,6 +755,7 @@ static int plan_nd(fc_plan* p) {
 
 int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   if (!desc || !out_plan) return fail(FC_ERR_INVALID, "null argument");
+  (void)hipGetLastError();   // a stale sticky error of an earlier, unrelated call (e.g. an invalidated capture) is not this call's
   *out_plan = nullptr;
   const fc_desc& d = *desc;
   if (d.ndim < 1 || d.ndim > 3) return fail(FC_ERR_INVALID, "ndim must be 1, 2 or 3 (got %d)", d.ndim);
@@ -789,6 +831,20 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
     p->workspace_bytes = 0;
     p->tile = nullptr;
     rc = FC_OK;
+    // 1-D, not transposed, at least 16 taps, dilated extent within half of a 2048-point tile: the FFT path in double
+    // precision (fft_f64.hip).  FFTCONV_F64_FFT=0 keeps the direct kernel (A/B runs, tests).
+    const char* env = getenv("FFTCONV_F64_FFT");
+    if ((!env || atoi(env) != 0) && d.ndim == 1 && !d.transposed && d.kernel[0] >= 16 && p->kd[0] <= 1025 &&
+        (int64_t)d.batch * d.groups * ((p->out_sp[0] + 255) / 256) < 0x40000000) {
+      int T = 256;
+      while (T < 2 * p->kd[0] && T < 2048) T *= 2;
+      p->f64_T = T;
+      p->f64_V = (int)(T - p->kd[0] + 1);
+      p->f64_ntiles = (int)((p->Lf[0] + p->f64_V - 1) / p->f64_V);
+      p->f64_cob = std::min(8, p->Cog);
+      p->Lfull = p->Lf[0];
+      p->spectrum_bytes = (size_t)d.out_channels * p->Cig * T * 2 * sizeof(double);
+    }
   } else if (d.ndim == 1) rc = plan_1d(p);
   else rc = plan_nd(p);
   if (rc != FC_OK) { delete p; return rc; }
@@ -810,7 +866,7 @@ int fc_output_shape(const fc_plan* plan, int64_t out_spatial[3]) {
 
 size_t fc_kernel_spectrum_bytes(const fc_plan* plan) { return plan ? plan->spectrum_bytes : 0; }
 size_t fc_workspace_bytes(const fc_plan* plan) { return plan ? plan->workspace_bytes : 0; }
-int fc_plan_tile(const fc_plan* plan) { return plan && plan->tile ? plan->tile->T : 0; }
+int fc_plan_tile(const fc_plan* plan) { return plan ? (plan->tile ? plan->tile->T : plan->f64_T) : 0; }
 
 // ---- 1-D weight gradient
 namespace {
@@ -884,6 +940,7 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
 int fc_wgrad1d_db(const fc_desc* desc, const float* x, const float* dy, float* partial, float* db_partial,
                   long long slice_stride, int slices, void* hip_stream) {
   if (!desc || !x || !dy || !partial) return fail(FC_ERR_INVALID, "null argument");
+  (void)hipGetLastError();   // a stale sticky error of an earlier, unrelated call (e.g. an invalidated capture) is not this call's
   WgradGeom g;
   if (!wgrad_geometry(*desc, &g)) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad1d does not cover this shape");
   if (db_partial && g.diag) return fail(FC_ERR_UNSUPPORTED, "the depthwise weight-gradient kernel has no bias-gradient output "
@@ -948,11 +1005,28 @@ long long fc_debug_grid(const fc_plan* plan) {
   return (long long)plan->d.batch * plan->ntiles * plan->n_ochunks * plan->G;
 }
 
+static void fill_f64_args(const fc_plan& p, fc::FftF64Args* a) {
+  a->B = (int)p.d.batch; a->Cin = (int)p.d.in_channels; a->Cout = (int)p.d.out_channels; a->G = (int)p.d.groups;
+  a->Cig = p.Cig; a->Cog = p.Cog;
+  a->L = (int)p.d.spatial[0]; a->pad = (int)p.d.padding[0]; a->pad_mode = p.d.padding_mode;
+  a->K = (int)p.d.kernel[0]; a->dil = (int)p.d.dilation[0]; a->stride = (int)p.d.stride[0];
+  a->T = p.f64_T; a->V = p.f64_V; a->ntiles = p.f64_ntiles; a->Lfull = p.Lf[0]; a->Lout = (int)p.out_sp[0];
+  a->cob = p.f64_cob; a->n_ochunks = (p.Cog + p.f64_cob - 1) / p.f64_cob;
+}
+
 int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, void* workspace, void* hip_stream) {
   if (!plan || !weight || !w_hat) return fail(FC_ERR_INVALID, "null argument");
+  (void)hipGetLastError();   // a stale sticky error of an earlier, unrelated call (e.g. an invalidated capture) is not this call's
   (void)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
   const fc_plan& p = *plan;
+  if (p.d.dtype == FC_F64 && p.f64_T) {
+    fc::FftF64Args a{};
+    fill_f64_args(p, &a);
+    a.w = (const double*)weight; a.wspec = (double2*)w_hat;
+    FC_HIP(fc::launch_fft_f64(0, a, st));
+    return FC_OK;
+  }
   if (p.d.dtype == FC_F64) {
     FC_HIP(hipMemcpyAsync(w_hat, weight, p.spectrum_bytes, hipMemcpyDeviceToDevice, st));
     return FC_OK;
@@ -1051,10 +1125,20 @@ int fc_forward(const fc_plan* plan, const float* x, const void* w_hat, const flo
 int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, const float* bias, float* y,
                        void* workspace, void* hip_stream, void* stamps) {
   if (!plan || !x || !w_hat || !y) return fail(FC_ERR_INVALID, "null argument");
+  (void)hipGetLastError();   // a stale sticky error of an earlier, unrelated call (e.g. an invalidated capture) is not this call's
   (void)workspace;
   hipStream_t st = (hipStream_t)hip_stream;
   const fc_plan& p = *plan;
   if (p.d.has_bias && !bias) return fail(FC_ERR_INVALID, "plan was created with has_bias=1 but bias is NULL");
+  if (p.d.dtype == FC_F64 && p.f64_T) {
+    if (stamps) return fail(FC_ERR_UNSUPPORTED, "no timestamp hook in the float64 kernels");
+    fc::FftF64Args a{};
+    fill_f64_args(p, &a);
+    a.x = (const double*)x; a.wspec = (double2*)const_cast<void*>(w_hat); a.bias = p.d.has_bias ? (const double*)bias : nullptr;
+    a.y = (double*)y;
+    FC_HIP(fc::launch_fft_f64(1, a, st));
+    return FC_OK;
+  }
   if (p.d.dtype == FC_F64) {
     if (stamps) return fail(FC_ERR_UNSUPPORTED, "no timestamp hook in the float64 kernel");
     fc::DirectF64Args a{};

@@ -1,0 +1,43 @@
+"""float64 1-D convolution: FFT path (csrc/fft_f64.hip) against the direct kernel and torch.fft on the same GPU.
+Usage: python scripts/f64_check.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fft_conv_pytorch_amd import _native  # noqa: E402
+from fft_conv_pytorch_amd.functional import fft_conv  # noqa: E402
+
+dev = "cuda:0"
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e6
+
+
+for (B, C, L, K) in ((1, 8, 32768, 128), (1, 8, 32768, 512), (8, 8, 32768, 512), (32, 8, 32768, 512), (4, 16, 65536, 1025)):
+    x = torch.randn(B, C, L, device=dev, dtype=torch.float64)
+    w = torch.randn(C, C, K, device=dev, dtype=torch.float64)
+    b = torch.randn(C, device=dev, dtype=torch.float64)
+    res = {}
+    for knob in ("1", "0"):
+        os.environ["FFTCONV_F64_FFT"] = knob
+        _native.clear_plan_cache()
+        y = fft_conv(x, w, b)
+        res[knob] = (timed(lambda: fft_conv(x, w, b)), y)
+    n = L
+    yref = torch.fft.irfft(torch.einsum("bif,oif->bof", torch.fft.rfft(x, n), torch.fft.rfft(w, n).conj()), n)[..., : L - K + 1] + b[None, :, None]
+    t_fft = timed(lambda: torch.fft.irfft(torch.einsum("bif,oif->bof", torch.fft.rfft(x, n), torch.fft.rfft(w, n).conj()), n))
+    err = float((res["1"][1] - yref).abs().max() / yref.abs().max())
+    print(f"B{B} {C}->{C} L{L} k{K}: FFT path {res['1'][0]:9.1f} us, direct kernel {res['0'][0]:9.1f} us "
+          f"({res['0'][0] / res['1'][0]:.1f}x), torch.fft formulation {t_fft:9.1f} us; rel err vs torch.fft {err:.2e}", flush=True)
+os.environ.pop("FFTCONV_F64_FFT", None)

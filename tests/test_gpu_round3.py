@@ -1,0 +1,256 @@
+"""GPU tests added in round 3: the plane-major 3-D pipeline against the separable passes and torch, the bias gradient
+folded into the weight-gradient launch, the explicit padding adjoints of the backward, plan creation versus stream
+capture, the 32-bit guards of the many-channel plan, the float64 FFT path and the planner's small-batch choice.
+Every call goes through the C ABI (fft_conv_pytorch_amd._native)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-4      # north_star bound (fp32, relative to the tensor's max magnitude)
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+# ----------------------------------------------------------------------------- plane-major 3-D pipeline (row N3)
+PLANE_CASES = [
+    # B, Cin, Cout, groups, size, k, stride, padding, dilation, mode
+    (2, 8, 8, 1, (64, 64, 64), (9, 9, 9), 1, 0, 1, "constant"),              # cfgC at batch 2
+    (1, 8, 8, 1, (64, 64, 64), (2, 4, 8), 1, 0, 1, "constant"),              # README shape, one batch item (NB = 1 build)
+    (3, 5, 7, 1, (40, 50, 60), (3, 4, 5), 1, 1, 1, "constant"),              # odd batch, ragged channel counts
+    (2, 8, 16, 1, (30, 33, 47), (5, 3, 2), (2, 1, 3), (2, 1, 0), 1, "constant"),   # strides, two output chunks
+    (2, 16, 8, 2, (20, 60, 62), (3, 3, 3), 1, 1, 1, "reflect"),              # groups, index-map padding
+    (2, 8, 8, 1, (21, 40, 40), (3, 5, 5), 1, 2, (1, 2, 3), "circular"),      # dilation
+    (2, 6, 6, 1, (17, 33, 20), (2, 3, 3), (1, 2, 1), 1, 1, "replicate"),
+    (2, 8, 8, 1, (150, 40, 40), (9, 3, 3), 1, 0, 1, "constant"),             # several overlap-save tiles along z
+    (1, 8, 8, 1, (100, 20, 20), (33, 3, 3), (3, 1, 1), 4, 1, "constant"),    # longest z kernel of the path, z stride
+]
+
+
+@pytest.mark.parametrize("case", PLANE_CASES, ids=[f"{c[4]}k{c[5]}{c[9]}" for c in PLANE_CASES])
+def test_planes3d_matches_separable_passes_and_torch(case, monkeypatch):
+    """planes_fwd / colz / planes_inv (csrc/planes3d.hpp) against the five separable passes (FFTCONV_PLANES=0) and
+    torch's direct convolution in float64: same function, three launches, plane-major intermediates."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv
+    B, Ci, Co, g, size, k, s, p, d, mode = case
+    gen = torch.Generator().manual_seed(1000 + sum(case[4]) + case[0])
+    x = torch.randn(B, Ci, *size, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci // g, *k, generator=gen) / math.sqrt(Ci // g * math.prod(k))).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("FFTCONV_PLANES", knob)          # (read at plan creation)
+        _native.clear_plan_cache()
+        outs[knob] = fft_conv(x, w, b, stride=s, padding=p, dilation=d, groups=g, padding_mode=mode)
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    if mode == "constant":
+        want = F.conv3d(xd, wd, bd, stride=s, padding=p, dilation=d, groups=g)
+    else:
+        pp = (p,) * 3 if isinstance(p, int) else p
+        want = F.conv3d(F.pad(xd, [q for ax in reversed(pp) for q in (ax, ax)], mode=mode), wd, bd, stride=s, dilation=d, groups=g)
+    assert outs["1"].shape == want.shape and outs["1"].is_contiguous()
+    assert _rel(outs["1"], want) < REL_TOL and _rel(outs["0"], want) < REL_TOL
+    assert _rel(outs["1"], outs["0"]) < 5e-6                 # the two pipelines agree to fp32 rounding
+    monkeypatch.delenv("FFTCONV_PLANES", raising=False)
+    _native.clear_plan_cache()
+
+
+def test_planes3d_transposed_and_backward():
+    """The transposed op and the gradients ride the same plans (dX of a 3-D convolution is a transposed plan whose
+    padded extent still fits the 64-point planes)."""
+    from fft_conv_pytorch_amd.functional import fft_conv, fft_conv_transpose
+    gen = torch.Generator().manual_seed(33)
+    x = torch.randn(2, 8, 20, 20, 20, generator=gen)
+    w = torch.randn(8, 6, 3, 3, 3, generator=gen) / 10
+    b = torch.randn(6, generator=gen)
+    want = F.conv_transpose3d(x.double(), w.double(), b.double(), stride=2, padding=1, output_padding=1)
+    got = fft_conv_transpose(x.to(DEV), w.to(DEV), b.to(DEV), stride=2, padding=1, output_padding=1)
+    assert _rel(got, want) < REL_TOL
+    xs = torch.randn(2, 8, 40, 48, 56, generator=gen)
+    ws = torch.randn(8, 8, 3, 5, 4, generator=gen) / 20
+    bs = torch.randn(8, generator=gen)
+    xr, wr, br = (t.clone().double().requires_grad_() for t in (xs, ws, bs))
+    F.conv3d(xr, wr, br, padding=2).square().sum().backward()
+    xg, wg, bg = (t.to(DEV).requires_grad_() for t in (xs, ws, bs))
+    fft_conv(xg, wg, bg, padding=2).square().sum().backward()
+    for got_g, want_g in ((xg.grad, xr.grad), (wg.grad, wr.grad), (bg.grad, br.grad)):
+        assert _rel(got_g, want_g) < REL_TOL
+
+
+# ----------------------------------------------------------------------------- backward: db in the dW launch, padding adjoints
+@pytest.mark.parametrize("mode,pad", [("constant", 5), ("reflect", 7), ("replicate", 4), ("circular", 9)])
+def test_bias_gradient_rides_the_weight_gradient_launch(mode, pad):
+    """1-D, stride 1: fc_wgrad1d_db returns rows [dW | db] per slice (db = bin 0 of the gradient spectra) and ONE
+    reduction sums both; the input gradient of a non-zero padding mode folds its border samples back explicitly.
+    Against torch's autograd in float64, long rows (many tiles and slices), a kernel that runs in tap segments too."""
+    from fft_conv_pytorch_amd import FFTConv1d, _native
+    for cin, cout, g, L, k, dil in ((8, 8, 1, 20000, 129, 1), (16, 24, 2, 9000, 33, 3), (8, 8, 1, 6000, 900, 1)):
+        torch.manual_seed(L + k)
+        layer = FFTConv1d(cin, cout, k, padding=pad, dilation=dil, groups=g, padding_mode="zeros" if mode == "constant" else mode).to(DEV)
+        x = torch.randn(3, cin, L, device=DEV, requires_grad=True)
+        desc = _native.conv_desc(1, 3, cin, cout, g, (L,), (k,), (1,), (pad,), (dil,), _native.PAD_MODES[mode])
+        assert _native.wgrad1d_db_supported(desc)             # (dense kernel: the fold is on)
+        y = layer(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        xr = x.detach().double().cpu().requires_grad_()
+        wr = layer.weight.detach().double().cpu().requires_grad_()
+        br = layer.bias.detach().double().cpu().requires_grad_()
+        xp = F.pad(xr, (pad, pad), mode=mode) if mode != "constant" else F.pad(xr, (pad, pad))
+        F.conv1d(xp, wr, br, dilation=dil, groups=g).backward(gy.double().cpu())
+        assert _rel(layer.bias.grad, br.grad) < REL_TOL
+        assert _rel(layer.weight.grad, wr.grad) < REL_TOL
+        assert _rel(x.grad, xr.grad) < REL_TOL
+
+
+def test_padding_adjoint_helper_matches_autograd():
+    """autograd._pad_adjoint (slice-adds on the border planes) against torch's own backward of F.pad, 1-3 axes."""
+    from fft_conv_pytorch_amd.autograd import _pad_adjoint
+    gen = torch.Generator().manual_seed(5)
+    for mode in ("reflect", "replicate", "circular"):
+        for size, pad in (((19,), (4,)), ((9, 12), (3, 0)), ((7, 8, 6), (2, 3, 1))):
+            probe = torch.randn(2, 3, *size, generator=gen, dtype=torch.float64, requires_grad=True)
+            flat = [q for p in reversed(pad) for q in (p, p)]
+            padded = F.pad(probe, flat, mode=mode)
+            g = torch.randn(padded.shape, generator=gen, dtype=torch.float64)
+            want, = torch.autograd.grad(padded, probe, g)
+            got = _pad_adjoint(g.to(DEV), size, pad, mode)
+            assert torch.allclose(got.cpu(), want, rtol=0, atol=1e-12), (mode, size, pad)
+
+
+# ----------------------------------------------------------------------------- plan creation and stream capture
+def test_warm_plans_capture_and_cold_plans_say_why_not():
+    """Plan creation allocates device tables with synchronous calls, so it must happen before a capture; a shape that
+    has run once is captured and replayed like any kernel launch (bench.py does exactly that).  A COLD shape inside a
+    capture fails with an error that names the fix instead of a bare HIP code (checked in a child process: a failed
+    capture leaves torch's capture stream unusable for the rest of the process)."""
+    import os
+    import subprocess
+    import sys
+    from fft_conv_pytorch_amd import FFTConv1d
+    torch.manual_seed(0)
+    layer = FFTConv1d(8, 8, 65, bias=True).to(DEV).eval()
+    x = torch.randn(4, 8, 9000, device=DEV)
+    with torch.no_grad():
+        want = layer(x).clone()                                # warm: plan, twiddles, work list, spectrum
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y = layer(x)
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from fft_conv_pytorch_amd import FFTConv2d\n"
+        "cold = FFTConv2d(8, 8, 5, bias=False).to('cuda:0').eval()\n"
+        "x = torch.randn(2, 8, 300, 700, device='cuda:0')\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "try:\n"
+        "    with torch.no_grad(), torch.cuda.graph(g):\n"
+        "        cold(x)\n"
+        "    print('CAPTURED')\n"
+        "except Exception as exc:\n"
+        "    while exc is not None:\n"
+        "        print('MSG', str(exc).replace(chr(10), ' ')[:400])\n"
+        "        exc = exc.__context__\n"
+    )
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    out = res.stdout
+    assert "CAPTURED" in out or "before the capture" in out, (out[-2000:], res.stderr[-2000:])
+
+
+# ----------------------------------------------------------------------------- many-channel plan: 32-bit guards
+def test_dense_plan_is_refused_beyond_its_32_bit_offsets():
+    """dense_inv marks dead stores with bit 31 of an offset into ONE group's output rows: Cog * Lout * 4 bytes must stay
+    below 2 GiB.  A shape beyond it keeps the fused kernels (plan layout word 6 != 2); just below it the pipeline runs.
+    Plan creation only: no tensor of that size is needed."""
+    from fft_conv_pytorch_amd import _native
+
+    def layout_word6(cout, length):
+        key = (1, 1, 32, cout, 1, (length,), (65,), (1,), (0,), (1,), 0, False, 0, False, (0,), 0)
+        with torch.cuda.device(0):
+            plan = _native.Plan(key, 0)
+        return plan.layout[6]
+
+    assert layout_word6(256, 1 << 20) == 2                   # 256 x 2^20 x 4 = 1 GiB per group: many-channel pipeline
+    assert layout_word6(256, (1 << 21) + 64) != 2            # 2 GiB and a bit: refused, fused kernels instead
+
+
+# ----------------------------------------------------------------------------- planner: small batches (bench cfgA_shard)
+def test_small_batch_plans_spread_over_more_workgroups():
+    """B = 4 rows of 32768 (one GPU's share of cfgA on an 8-GPU node): 63 four-slot items would leave three quarters of
+    the CUs idle; the launch-time model picks the two-slot kernel (126 workgroups).  The result is the same function."""
+    from fft_conv_pytorch_amd import FFTConv1d
+    torch.manual_seed(1)
+    layer = FFTConv1d(8, 8, 512, bias=True).to(DEV).eval()
+    x = torch.randn(4, 8, 32768, device=DEV)
+    with torch.no_grad():
+        y = layer(x)
+    plan = layer.__dict__["_spectrum_cache"][1].plan
+    assert plan.tile == 1024 and plan.layout[7] == 2, plan.layout
+    want = F.conv1d(x.double(), layer.weight.double(), layer.bias.double())
+    assert _rel(y, want) < REL_TOL
+
+
+# ----------------------------------------------------------------------------- float64 through an FFT path (row N4)
+F64_CASES = [
+    # B, Cin, Cout, groups, L, k, stride, padding, dilation, mode
+    (1, 8, 8, 1, 32768, 128, 1, 0, 1, "constant"),        # cfg0 in float64
+    (2, 6, 10, 2, 5000, 33, 2, 7, 3, "reflect"),          # groups, stride, dilation, 97-sample extent
+    (3, 5, 3, 1, 1234, 16, 1, 15, 1, "circular"),         # shortest kernel of the path, ragged channels
+    (2, 12, 12, 1, 9000, 513, 1, 256, 2, "replicate"),    # 1025-sample extent: the 2048-point tile
+    (1, 4, 4, 4, 700, 100, 3, 0, 1, "constant"),          # depthwise, stride 3
+]
+
+
+@pytest.mark.parametrize("case", F64_CASES, ids=[f"L{c[4]}k{c[5]}{c[9]}" for c in F64_CASES])
+def test_float64_fft_path_matches_torch_and_the_direct_kernel(case, monkeypatch):
+    """float64 tensors of a 1-D convolution run overlap-save tiles through a double-precision transform
+    (csrc/fft_f64.hip) like the reference's complex128 FFTs (functional.py:19-89), not the O(taps) direct kernel:
+    within 1e-10 of torch's float64 convolution, and of the direct kernel (FFTCONV_F64_FFT=0)."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import _plan_for, fft_conv
+    B, Ci, Co, g, L, k, s, p, d, mode = case
+    gen = torch.Generator().manual_seed(L + k)
+    x = torch.randn(B, Ci, L, generator=gen, dtype=torch.float64).to(DEV)
+    w = torch.randn(Co, Ci // g, k, generator=gen, dtype=torch.float64).to(DEV)
+    b = torch.randn(Co, generator=gen, dtype=torch.float64).to(DEV)
+    outs = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("FFTCONV_F64_FFT", knob)          # (read at plan creation)
+        _native.clear_plan_cache()
+        outs[knob] = fft_conv(x, w, b, stride=s, padding=p, dilation=d, groups=g, padding_mode=mode)
+        plan = _plan_for(x, w, b, s, p, d, g, mode)
+        assert (plan.tile > 0) == (knob == "1")              # an FFT tile, or the direct kernel
+    xc = x.cpu()
+    if mode != "constant" and p:
+        want = F.conv1d(F.pad(xc, (p, p), mode=mode), w.cpu(), b.cpu(), stride=s, dilation=d, groups=g)
+    else:
+        want = F.conv1d(xc, w.cpu(), b.cpu(), stride=s, padding=p, dilation=d, groups=g)
+    assert outs["1"].dtype == torch.float64 and outs["1"].shape == want.shape
+    assert _rel(outs["1"], want) < 1e-10 and _rel(outs["0"], want) < 1e-10
+    monkeypatch.delenv("FFTCONV_F64_FFT", raising=False)
+    _native.clear_plan_cache()
+
+
+def test_float64_module_trains_through_the_fft_path():
+    from fft_conv_pytorch_amd import FFTConv1d
+    torch.manual_seed(3)
+    layer = FFTConv1d(6, 6, 65, padding=32, bias=True).to(DEV).double()
+    x = torch.randn(2, 6, 3000, device=DEV, dtype=torch.float64, requires_grad=True)
+    layer(x).square().sum().backward()
+    xr = x.detach().cpu().requires_grad_()
+    wr, br = layer.weight.detach().cpu().requires_grad_(), layer.bias.detach().cpu().requires_grad_()
+    F.conv1d(xr, wr, br, padding=32).square().sum().backward()
+    assert _rel(x.grad, xr.grad) < 1e-10 and _rel(layer.weight.grad, wr.grad) < 1e-10 and _rel(layer.bias.grad, br.grad) < 1e-10

@@ -278,8 +278,11 @@ def main():
 
     steps, warmup = args.steps, args.warmup
     graph = None
+    # launches per graph: whole rotations over the buffer sets, as many as the timed steps hold (at most 64 rotations),
+    # so that K timed steps are a few replays plus at most nbuf - 1 eager launches whatever K is (a replay costs the host
+    # 10-16 us: with one rotation per graph the driver's 20-step run paid two replays and two eager launches for 20 steps)
+    per_graph = nbuf * max(1, min(64, steps // nbuf))
     if not args.no_graph:
-        # one rotation over the buffer sets per graph; a remainder of steps is launched eagerly
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(stream)
         with torch.cuda.stream(side):
@@ -289,14 +292,14 @@ def main():
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(nbuf):
+            for i in range(per_graph):
                 step(i)
 
     def run(n):
         if graph is not None:
-            for _ in range(n // nbuf):
+            for _ in range(n // per_graph):
                 graph.replay()
-            for i in range(n % nbuf):
+            for i in range(n % per_graph):
                 step(i)
         else:
             for i in range(n):
@@ -310,7 +313,7 @@ def main():
     # device spin-up (untimed, not counted as steps): the clock takes tens of milliseconds of load to settle
     t_spin = time.perf_counter()
     while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:
-        run(4 * nbuf)
+        run(max(4 * nbuf, per_graph))
         torch.cuda.synchronize(dev)
     run(warmup)
     fence()
@@ -345,7 +348,8 @@ def main():
             "config": {"workload": f"{args.config}: {ndim}D fft_conv B={batch}/GPU"
                                    f"{' (of ' + str(total_batch) + ' over the node)' if args.scaling == 'strong' else ''} {cin}->{cout}ch groups={groups} "
                                    f"spatial={list(spatial)} kernel={list(kernel)} dilation={dil} bias, fp32",
-                       "tile": plan.tile, "buffer_sets": nbuf, "hip_graph": graph is not None, "spinup_ms": args.spinup_ms,
+                       "tile": plan.tile, "buffer_sets": nbuf, "hip_graph": graph is not None, "launches_per_graph": per_graph if graph is not None else 0,
+                       "spinup_ms": args.spinup_ms,
                        "kernel_spectrum": "cached per weight version (FFTConv module)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, dominant_kernel_name(plan)),

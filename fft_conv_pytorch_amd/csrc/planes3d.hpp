@@ -261,7 +261,9 @@ constexpr size_t colz_lds_bytes(int nb) { return (size_t)2 * nb * 8 * 16 * (colz
 // NB batch items per workgroup (1, 2 or 4) share every kernel-spectrum load.  A chunk of FC frequencies x 16 columns
 // is mixed by NB*128 threads: R = NB*8/FC threads per bin, each owning 8/R output channels (with NB = 4 the two
 // halves of the workgroup).  RING spectrum sets (one output channel x 8 inputs = 4 float4) travel per thread.
-template <int NB, int RING, bool STAMPS = false>
+// DIAG (timestamp builds only, FFTCONV_COLZ_DIAG): 1 = the kernel-spectrum loads are replaced by register constants,
+// 2 = no LDS exchange barriers' partner work (the mix arithmetic is skipped) -- what-bounds-the-mix experiments.
+template <int NB, int RING, bool STAMPS = false, int DIAG = 0>
 __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   constexpr int NT = NB * 128;
   constexpr int FC = colz_fc(NB);
@@ -343,6 +345,15 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
     // (rows past the chunk's last output channel lie outside the spectrum buffer: the scalar offset is not part of
     // the range check, so those loads are switched off through the lane offset)
     const unsigned vo = h * SPC + k < a.cob ? wvo + (unsigned)(chunk * FC * 16) : 0x80000000u;
+    if constexpr (DIAG == 1) {
+#pragma unroll
+      for (int ip = 0; ip < 4; ++ip) {
+        f4 q; q.x = 1e-3f * (float)(st + ip); q.y = q.x; q.z = q.x; q.w = q.x;
+        asm volatile("" : "+v"(q));
+        ring[st % RING][ip] = q;
+      }
+      return;
+    }
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip)
       ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (kPlCols * 64 * 16)));
@@ -388,22 +399,24 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
         constexpr int st = chunk * SPC + k;
         f4 (&w)[4] = ring[st % RING];
         const int o = h * SPC + k;
-        if (o < a.cob) {
+        if (o < a.cob && DIAG != 2) {
           static_for<0, NP>([&](auto pc) {
             constexpr int pr = decltype(pc)::value;
             if constexpr (NP > 1) load_x(pc);
-            f2 y[PB];
+            // (2 * PB independent accumulation chains -- even / odd input channels of every batch item: a chain of
+            // dependent v_pk_fma_f32 issues every 8 cycles, and the mix's arithmetic alone was 6.4 us of its 20)
+            f2 y[PB], y2[PB];
 #pragma unroll
-            for (int q = 0; q < PB; ++q) y[q] = mk2(0.f, 0.f);
+            for (int q = 0; q < PB; ++q) { y[q] = mk2(0.f, 0.f); y2[q] = mk2(0.f, 0.f); }
 #pragma unroll
             for (int ip = 0; ip < 4; ++ip) {
 #pragma unroll
               for (int q = 0; q < PB; ++q) cmac(y[q], x[q][2 * ip], w[ip].xy);
 #pragma unroll
-              for (int q = 0; q < PB; ++q) cmac(y[q], x[q][2 * ip + 1], w[ip].zw);
+              for (int q = 0; q < PB; ++q) cmac(y2[q], x[q][2 * ip + 1], w[ip].zw);
             }
 #pragma unroll
-            for (int q = 0; q < PB; ++q) yrow[((pr * PB + q) * 8 + o) * ROW] = y[q];
+            for (int q = 0; q < PB; ++q) yrow[((pr * PB + q) * 8 + o) * ROW] = y[q] + y2[q];
           });
         }
         if constexpr (st + RING < NCH * SPC) issue(std::integral_constant<int, st + RING>{});
@@ -448,6 +461,200 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
         const int t = t0 + n, idx = t / a.stride;
         const bool ok = live && n < limit && idx * a.stride == t;
         buf_store_f32x2(v[n], orr, ok ? vo + (unsigned)idx * (kPlCols * 8) : 0x80000000u, 0);
+      });
+    }
+  }
+  stampc(5, false);
+  stampc(6, true);
+  stampc(7, false);
+}
+
+// ------------------------------------------------------------------------------------------ colz, two threads per sequence
+// The mix of colz_kernel is bound by the LATENCY of its kernel-spectrum stream: the 64-point register transforms hold 128
+// VGPRs per thread, which leaves room for two spectrum sets in flight (64 KB per CU against 1 MB to stream at ~1.3 us per
+// load: 21 us, profiles/r03_experiments.md block 1).  Here a sequence is split over the two lanes of a pair -- lane h owns
+// the samples z = 2m + h, runs a 32-point register transform and meets its partner in ONE radix-2 stage through DPP (as the
+// engine's S = 2 split) -- so a thread carries 32 points (64 VGPRs) and the ring grows to RING sets.  512 threads = 2 batch
+// slots x 8 channels x 16 columns x 2 halves, one workgroup per CU; a chunk of 16 frequencies x 16 columns is mixed by two
+// threads per bin (each 4 of the 8 output channels).  After the forward stage lane h holds the bins f + 32 h, which is also
+// what the inverse stage wants; after the inverse lane h holds the samples 2m + h again: loads and stores mirror each other.
+constexpr size_t colz2_lds_bytes() { return (size_t)2 * 16 * 16 * 17 * sizeof(f2); }
+
+template <int RING, bool STAMPS = false>
+__global__ __launch_bounds__(512, 2) void colz2_kernel(const ColZArgs a) {
+  constexpr int NB = 2, NT = 512, FC = 16, NCH = 4, PF = FC + 1, ROW = 16 * PF, SPC = 4;
+  extern __shared__ __attribute__((aligned(16))) f2 lds[];
+  f2* xs = lds;                             // [NB*8][16][PF] forward spectra of the chunk
+  f2* ys = lds + NB * 8 * ROW;              // [NB*8][16][PF] mixed spectra of the chunk
+  const int tid = threadIdx.x;
+  auto stampc = [&](int slot, bool drain) {
+    if constexpr (STAMPS) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) a.stamps[(size_t)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  stampc(0, false);
+  int id = blockIdx.x;
+  const int xcd = id & 7; id >>= 3;
+  const int nbp = (a.B + NB - 1) / NB;
+  const int b0 = (id % nbp) * NB; id /= nbp;
+  const int colblk = xcd * (kPlCols / 128) + id % (kPlCols / 128); id /= (kPlCols / 128);
+  const int g = id % a.G; id /= a.G;
+  const int oc = id % a.n_ochunks;
+  const int tile = id / a.n_ochunks;
+  const int col0 = colblk * 16;
+  const int nbc = min(NB, a.B - b0);
+  const int t0 = tile * a.V;
+  unsigned zstep2 = 2 * kPlCols * 8;        // two planes (opaque scalar, see colz_kernel)
+  asm volatile("" : "+s"(zstep2));
+
+  // ---- sequence half owner: (batch slot nb, channel ch, column c, half h: samples z = 2m + h)
+  const int h = tid & 1, c = (tid >> 1) & 15, ch = (tid >> 5) & 7, nb = tid >> 8;
+  const float sgf = h ? -1.0f : 1.0f;
+  const f2 sg = mk2(sgf, sgf);
+  f2 v[32];
+  const int cend = min(a.cob, a.Cog - oc * a.cob);
+  f2* obase = a.dst + ((size_t)b0 * a.Cout + (size_t)g * a.Cog + (size_t)oc * a.cob) * a.NZo * kPlCols;
+  const BufRsrc orr = make_rsrc(obase, (unsigned)((((size_t)(nbc - 1) * a.Cout + cend) * a.NZo) * kPlCols * 8));
+  {
+    const f2* sbase = a.src + ((size_t)b0 * a.Cin + (size_t)g * a.Cig) * a.NZ * kPlCols;
+    const BufRsrc sr = make_rsrc(sbase, (unsigned)((((size_t)(nbc - 1) * a.Cin + a.Cig) * a.NZ) * kPlCols * 8));
+    const bool has_in = ch < a.Cig && nb < nbc;
+    const unsigned voff = has_in ? (unsigned)((((size_t)nb * a.Cin + ch) * a.NZ + t0 + h) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    if (t0 + 64 <= a.NZ) {
+      static_for<0, 32>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        v[m] = buf_load_f32x2(sr, voff, m * zstep2);
+      });
+    } else {
+      static_for<0, 32>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        v[m] = buf_load_f32x2(sr, (t0 + 2 * m + h < a.NZ) ? voff : 0x80000000u, m * zstep2);
+      });
+    }
+  }
+  // ---- bin owner: (share hh of the output channels, frequency fzl of the chunk, column cm)
+  const int hh = tid >> 8, fzl = tid & 15, cm = (tid >> 4) & 15;
+  const size_t wrow = (size_t)kPlCols * 64;
+  const f4* wbase = a.wspec + ((size_t)g * a.Cog_pad + (size_t)oc * a.cob) * 4 * wrow;
+  const BufRsrc wr_ = make_rsrc(wbase, (unsigned)((size_t)a.cob * 4 * wrow * 16));
+  const unsigned wvo = (unsigned)((col0 + cm) * 64 + fzl) * 16u + (unsigned)(hh * SPC * 4) * (unsigned)(kPlCols * 64 * 16);
+  f4 ring[RING][4];
+  auto issue = [&](auto stc) {
+    constexpr int st = decltype(stc)::value;
+    constexpr int chunk = st / SPC, k = st % SPC;
+    const unsigned vo = hh * SPC + k < a.cob ? wvo + (unsigned)(chunk * FC * 16) : 0x80000000u;
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip)
+      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (kPlCols * 64 * 16)));
+  };
+  constexpr int EARLY = RING < 3 ? RING : 3;                 // (the rest of the ring goes out behind the forward transform)
+  static_for<0, EARLY>([&](auto sc) { issue(sc); });
+  stampc(1, true);
+  // ---- forward: 32-point transform of this lane's samples, then the radix-2 stage across the lane pair
+  fft_regs<32, -1>(v);
+  if (h) {
+    static_for<1, 32>([&](auto fc_) {
+      constexpr int f = decltype(fc_)::value;
+      v[f] = cmul_const(v[f], cos64(f), -sin64(f));           // w_64^f
+    });
+  }
+#pragma unroll
+  for (int f = 0; f < 32; ++f) v[f] = pkfma(sg, v[f], dpp_xor1(v[f]));     // h = 0: E + t -> X[f]; h = 1: E - t -> X[f + 32]
+  static_for<EARLY, RING>([&](auto sc) { issue(sc); });
+  stampc(2, false);
+
+  static_for<0, NCH>([&](auto cc) {
+    constexpr int chunk = decltype(cc)::value;
+    if (h == chunk / 2) {                 // the chunk's 16 bins live in the lanes of one half
+      f2* xrow = xs + ((nb * 8 + ch) * 16 + c) * PF;
+#pragma unroll
+      for (int j = 0; j < FC; ++j) xrow[j] = v[(chunk % 2) * FC + j];
+    }
+    __syncthreads();
+    {
+      const unsigned xa = lds_off(xs + cm * PF + fzl);
+      f2* yrow = ys + cm * PF + fzl;
+      f2 x[NB][8];
+      static_for<0, NB>([&](auto bc) {
+        constexpr int bb = decltype(bc)::value;
+        static_for<0, 8>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          x[bb][i] = lds_rd<(bb * 8 + i) * ROW * 8>(xa);
+        });
+      });
+#pragma unroll
+      for (int q = 0; q < NB; ++q) lds_arrive(x[q]);
+      static_for<0, SPC>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int st = chunk * SPC + k;
+        f4 (&w)[4] = ring[st % RING];
+        const int o = hh * SPC + k;
+        if (o < a.cob) {
+          f2 y[NB];
+#pragma unroll
+          for (int q = 0; q < NB; ++q) y[q] = mk2(0.f, 0.f);
+#pragma unroll
+          for (int ip = 0; ip < 4; ++ip) {
+#pragma unroll
+            for (int q = 0; q < NB; ++q) cmac(y[q], x[q][2 * ip], w[ip].xy);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) cmac(y[q], x[q][2 * ip + 1], w[ip].zw);
+          }
+#pragma unroll
+          for (int q = 0; q < NB; ++q) yrow[(q * 8 + o) * ROW] = y[q];
+        }
+        if constexpr (st + RING < NCH * SPC) issue(std::integral_constant<int, st + RING>{});
+      });
+    }
+    __syncthreads();
+    if (h == chunk / 2) {
+      const f2* yrow = ys + ((nb * 8 + ch) * 16 + c) * PF;
+#pragma unroll
+      for (int j = 0; j < FC; ++j) v[(chunk % 2) * FC + j] = yrow[j];
+    }
+  });
+  stampc(3, false);
+  // ---- inverse: radix-2 stage across the pair, twiddle, 32-point transform -> samples z = 2m + h
+#pragma unroll
+  for (int f = 0; f < 32; ++f) v[f] = pkfma(sg, v[f], dpp_xor1(v[f]));     // h = 0: Y[f] + Y[f+32]; h = 1: Y[f] - Y[f+32]
+  if (h) {
+    static_for<1, 32>([&](auto fc_) {
+      constexpr int f = decltype(fc_)::value;
+      v[f] = cmul_const(v[f], cos64(f), sin64(f));            // w_64^(-f)
+    });
+  }
+  fft_regs<32, +1>(v);
+  stampc(4, false);
+  {
+    const bool live = nb < nbc && ch < a.cob && oc * a.cob + ch < a.Cog;
+    const int limit = min(a.V, a.Lfull - t0);
+    const unsigned vo = live ? (unsigned)((((size_t)nb * a.Cout + ch) * a.NZo) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    if (a.stride == 1) {
+      unsigned zstep_st = 2 * kPlCols * 8;
+      asm volatile("" : "+s"(zstep_st));
+      const unsigned vo1 = live ? vo + (unsigned)(t0 + h) * (kPlCols * 8) : 0x80000000u;
+      // blocks of 8 sample pairs: a block inside the valid window is straight-line code behind one scalar branch
+      static_for<0, 4>([&](auto bc) {
+        constexpr int m0 = 8 * decltype(bc)::value;
+        if (2 * (m0 + 8) <= limit) {
+          static_for<m0, m0 + 8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            buf_store_f32x2(v[m], orr, vo1, m * zstep_st);
+          });
+        } else if (2 * m0 < limit) {
+          static_for<m0, m0 + 8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            buf_store_f32x2(v[m], orr, 2 * m + h < limit ? vo1 : 0x80000000u, m * zstep_st);
+          });
+        }
+      });
+    } else {
+      static_for<0, 32>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        const int n = 2 * m + h, t = t0 + n, idx = t / a.stride;
+        const bool ok = live && n < limit && idx * a.stride == t;
+        buf_store_f32x2(v[m], orr, ok ? vo + (unsigned)idx * (kPlCols * 8) : 0x80000000u, 0);
       });
     }
   }

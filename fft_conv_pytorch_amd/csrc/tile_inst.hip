@@ -351,10 +351,10 @@ hipError_t planes_inv_dispatch(const PlaneInvArgs& a, int n_images, hipStream_t 
   hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
   return hipGetLastError();
 }
-template <int NB, bool STAMPS = false>
+template <int NB, bool STAMPS = false, int DIAG = 0>
 hipError_t launch_colz(const ColZArgs& a, hipStream_t st) {
   constexpr int RING = NB == 4 ? 3 : 2;
-  auto k = colz_kernel<NB, RING, STAMPS>;
+  auto k = colz_kernel<NB, RING, STAMPS, DIAG>;
   const size_t lds = colz_lds_bytes(NB);
   static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
@@ -365,12 +365,34 @@ hipError_t launch_colz(const ColZArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB * 128), lds, st, a);
   return hipGetLastError();
 }
+template <bool STAMPS = false>
+hipError_t launch_colz2(const ColZArgs& a, hipStream_t st) {
+  auto k = colz2_kernel<5, STAMPS>;
+  const size_t lds = colz2_lds_bytes();
+  static LdsOptIn done;
+  hipError_t e = ensure_lds(k, lds, &done);
+  if (e != hipSuccess) return e;
+  const long long nbp = (a.B + 1) / 2;
+  const long long grid = nbp * a.ntiles * a.n_ochunks * a.G * (kPlCols / 16);
+  if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(512), lds, st, a);
+  return hipGetLastError();
+}
 // batch items per workgroup: 2 (two workgroups per CU).  4 (one 512-thread workgroup per CU, half the spectrum traffic,
 // FFTCONV_COLZ_NB=4) measured slower at cfgC: mix 28.4 against 21.2 us per workgroup -- its inputs no longer stay in
 // registers across the output channels and the mix waits on LDS round trips instead (profiles/r03_experiments.md)
 hipError_t colz_dispatch(const ColZArgs& a, hipStream_t st) {
   static const int force = getenv("FFTCONV_COLZ_NB") ? atoi(getenv("FFTCONV_COLZ_NB")) : 0;
+  // two threads per sequence (colz2_kernel) for batches of two and more; FFTCONV_COLZ_NB = 1 / 2 / 4 forces the
+  // thread-per-sequence builds (A/B runs, tests)
+  // (the pair build measured no faster at cfgC -- 112.9 against 108.3 us per forward, profiles/r03_experiments.md block 5 --
+  // and stays behind FFTCONV_COLZ_PAIRS=1)
+  static const int pairs = getenv("FFTCONV_COLZ_PAIRS") ? atoi(getenv("FFTCONV_COLZ_PAIRS")) : 0;
+  if (pairs && force == 0 && a.B >= 2) return a.stamps ? launch_colz2<true>(a, st) : launch_colz2<false>(a, st);
   const int nb = (force == 1 || force == 2 || force == 4) ? force : (a.B >= 2 ? 2 : 1);
+  static const int diag = getenv("FFTCONV_COLZ_DIAG") ? atoi(getenv("FFTCONV_COLZ_DIAG")) : 0;    // experiments (wrong results)
+  if (a.stamps && nb == 2 && diag == 1) return launch_colz<2, true, 1>(a, st);
+  if (a.stamps && nb == 2 && diag == 2) return launch_colz<2, true, 2>(a, st);
   if (a.stamps) return nb == 4 ? launch_colz<4, true>(a, st) : (nb == 2 ? launch_colz<2, true>(a, st) : launch_colz<1, true>(a, st));
   return nb == 4 ? launch_colz<4>(a, st) : (nb == 2 ? launch_colz<2>(a, st) : launch_colz<1>(a, st));
 }

@@ -838,10 +838,20 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
         (int64_t)d.batch * d.groups * ((p->out_sp[0] + 255) / 256) < 0x40000000) {
       int T = 256;
       while (T < 2 * p->kd[0] && T < 2048) T *= 2;
+      // a longer tile wastes less of itself on the overlap; taken while the launch still has two workgroups per CU
+      while (T < 2048) {
+        const int64_t V2 = 2 * T - p->kd[0] + 1, tiles2 = (p->Lf[0] + V2 - 1) / V2;
+        if (d.batch * d.groups * ((p->Cog + 7) / 8) * tiles2 < 512) break;
+        T *= 2;
+      }
       p->f64_T = T;
       p->f64_V = (int)(T - p->kd[0] + 1);
       p->f64_ntiles = (int)((p->Lf[0] + p->f64_V - 1) / p->f64_V);
-      p->f64_cob = std::min(8, p->Cog);
+      // output channels per workgroup: 8, fewer (even) while the launch would leave CUs idle -- a workgroup's life is its
+      // transforms in a row (Cig/2 forward + cob/2 inverse), so small launches gain from more, shorter workgroups
+      int cob = 8;
+      while (cob > 2 && d.batch * d.groups * ((p->Cog + cob - 1) / cob) * p->f64_ntiles < 256) cob /= 2;   // (fewer workgroups than CUs)
+      p->f64_cob = std::min(cob, std::max(p->Cog, 1));
       p->Lfull = p->Lf[0];
       p->spectrum_bytes = (size_t)d.out_channels * p->Cig * T * 2 * sizeof(double);
     }

@@ -5,7 +5,7 @@
 // This file is the same 1-D algorithm as the fp32 kernels -- overlap-save tiles, forward transform, per-bin channel
 // contraction against the pre-transformed kernel, inverse transform, valid window + stride + bias -- written in plain
 // double precision: a Stockham radix-2 transform in LDS (natural order in and out, one butterfly per thread and stage,
-// twiddles from a table the workgroup builds with sincospi), one real channel per complex sequence, the output
+// twiddles from a table the workgroup builds with sincospi), two real channels per complex sequence, the output
 // channels' spectra accumulated in registers over the input channels (a thread owns bins t and t + T/2).  It is not
 // tuned like the packed-fp32 engine (fft_engine.hpp is written on v_pk_*_f32 pairs and 8-byte LDS slots); it exists so
 // that float64 results come from the same transform-domain arithmetic as the reference's at FFT cost.  2-D / 3-D and
@@ -103,46 +103,68 @@ __global__ __launch_bounds__(1024) void conv1d_f64_kernel(const FftF64Args a) {
   double2 acc[8][2];
 #pragma unroll
   for (int o = 0; o < 8; ++o) acc[o][0] = acc[o][1] = make_double2(0.0, 0.0);
-  for (int i = 0; i < a.Cig; ++i) {
-    const double* xrow = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig + i) * a.L;
-    __syncthreads();                                   // (table built / previous channel's spectrum consumed)
+  // two real input channels ride one complex transform (z = x_a + i x_b; X_a[f] = (Z[f] + conj Z[T-f]) / 2,
+  // X_b[f] = (Z[f] - conj Z[T-f]) / 2i), two output channels one inverse transform
+  for (int i = 0; i < a.Cig; i += 2) {
+    const bool two = i + 1 < a.Cig;
+    const double* xa = a.x + ((size_t)b * a.Cin + (size_t)g * a.Cig + i) * a.L;
+    const double* xb = xa + a.L;
+    __syncthreads();                                   // (table built / previous pair's spectrum consumed)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int n = t + h * half;
       const int q = src_index_d(pos0 + n, a.L, a.pad, a.pad_mode);
-      bufA[n] = make_double2(q >= 0 ? xrow[q] : 0.0, 0.0);
+      bufA[n] = make_double2(q >= 0 ? xa[q] : 0.0, (q >= 0 && two) ? xb[q] : 0.0);
     }
     __syncthreads();
-    const double2* X = fft_stockham<-1>(bufA, bufB, tw, T, t);
-    const double2 x0 = X[t], x1 = X[t + half];
+    const double2* Z = fft_stockham<-1>(bufA, bufB, tw, T, t);
+    double2 xs[2][2];                                  // [bin t / t + half][channel a / b]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = t + h * half;
+      const double2 zf = Z[f], zg = Z[(T - f) & (T - 1)];
+      xs[h][0] = make_double2(0.5 * (zf.x + zg.x), 0.5 * (zf.y - zg.y));
+      xs[h][1] = make_double2(0.5 * (zf.y + zg.y), 0.5 * (zg.x - zf.x));
+    }
     const double2* hrow = a.wspec + (((size_t)g * a.Cog + (size_t)oc * a.cob) * a.Cig + i) * T;
 #pragma unroll
     for (int o = 0; o < 8; ++o)
       if (o < nout) {
         const double2* hp = hrow + (size_t)o * a.Cig * T;
-        const double2 p0 = cmul_d(x0, hp[t]), p1 = cmul_d(x1, hp[t + half]);
-        acc[o][0].x += p0.x; acc[o][0].y += p0.y;
-        acc[o][1].x += p1.x; acc[o][1].y += p1.y;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int f = t + h * half;
+          double2 p = cmul_d(xs[h][0], hp[f]);
+          if (two) { const double2 p2 = cmul_d(xs[h][1], hp[T + f]); p.x += p2.x; p.y += p2.y; }
+          acc[o][h].x += p.x; acc[o][h].y += p.y;
+        }
       }
   }
   const int t0 = tile * a.V;
   const int limit = min(a.V, a.Lfull - t0);
 #pragma unroll
-  for (int o = 0; o < 8; ++o) {
+  for (int o = 0; o < 8; o += 2) {
     if (o >= nout) break;                              // uniform
+    const bool two = o + 1 < nout;
     __syncthreads();
-    bufA[t] = acc[o][0];
-    bufA[t + half] = acc[o][1];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const double2 ya = acc[o][h], yb = two ? acc[o + 1][h] : make_double2(0.0, 0.0);
+      bufA[t + h * half] = make_double2(ya.x - yb.y, ya.y + yb.x);      // Y_a + i Y_b
+    }
     __syncthreads();
     const double2* Y = fft_stockham<+1>(bufA, bufB, tw, T, t);
     const int co = g * a.Cog + oc * a.cob + o;
-    const double bias = a.bias ? a.bias[co] : 0.0;
+    const double bias_a = a.bias ? a.bias[co] : 0.0, bias_b = (a.bias && two) ? a.bias[co + 1] : 0.0;
     double* yrow = a.y + ((size_t)b * a.Cout + co) * a.Lout;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int n = t + h * half;
       const int pos = t0 + n, idx = pos / a.stride;
-      if (n < limit && idx * a.stride == pos) yrow[idx] = Y[n].x + bias;
+      if (n < limit && idx * a.stride == pos) {
+        yrow[idx] = Y[n].x + bias_a;
+        if (two) yrow[a.Lout + idx] = Y[n].y + bias_b;
+      }
     }
   }
 }

@@ -84,7 +84,7 @@ class _FFTConvForward(_SpectrumCache, nn.Module):
     def forward(self, signal: Tensor):
         assert signal.ndim == self.weight.ndim
         padding_mode = "constant" if self.padding_mode == "zeros" else self.padding_mode
-        if isinstance(self.padding, str) or signal.dtype != torch.float32:
+        if isinstance(self.padding, str) or signal.dtype not in (torch.float32, torch.float64):
             # padding='same' / 'valid' (torch stores the string) and half-precision inputs: the functional resolves them
             return F_._fft_conv_impl(signal, self.weight, self.bias, self.stride, self.padding, self.dilation,
                                      self.groups, padding_mode, None)

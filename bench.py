@@ -80,7 +80,8 @@ def pmc_traffic(config_name, kernel_name):
             continue
         for entry in prof.get("entries", [prof]):
             if entry.get("workload") == config_name and kernel_name and kernel_name in entry.get("kernel", ""):
-                return entry.get("traffic_bytes_per_launch")
+                # a forward of several launches (2-D / 3-D): the traffic of all of them, as `achieved` is over all of them
+                return entry.get("whole_forward_traffic_bytes", entry.get("traffic_bytes_per_launch"))
     return None
 
 

@@ -166,6 +166,12 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     }
     if (interior && has1 && !PHASES) {
       const unsigned v0 = ro0 + (unsigned)(pos0 + tseq) * 4u, v1 = ro1 + (unsigned)(pos0 + tseq) * 4u;
+#if FC_DIAG == 7
+#pragma unroll
+      for (int n1 = 0; n1 < P; ++n1) { v[n1] = mk2(1e-3f * n1, (float)tseq); asm volatile("" : "+v"(v[n1])); }
+      (void)v0; (void)v1;
+      return;
+#endif
 #pragma unroll
       for (int n1 = 0; n1 < P; ++n1) {
         v[n1].x = buf_load_f32(xg, v0, G::N2 * n1 * 4);
@@ -249,8 +255,15 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       const int j = passB_compute<G, -1>(v, tseq, twB);
       const int k1 = tseq >> G::LGS;
       f2* dst = zseq + G::nat(k1 + P * P * j);
+#if FC_DIAG == 2
+      { f2 sink = v[0];
+#pragma unroll
+        for (int k = 1; k < P; ++k) sink += v[k];
+        if (sink.x == 123.456f) dst[0] = sink; }
+#else
 #pragma unroll
       for (int k = 0; k < P; ++k) dst[P * k] = v[k];
+#endif
     }
     // ------------------------------------------------ mix, depthwise: every channel meets only its own kernel
     if constexpr (DIAG) {
@@ -369,8 +382,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
           f2 ya = mk2(0.f, 0.f), yb = mk2(0.f, 0.f);
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
-            cmac(ya, xe[hp][2 * p], wc[p].xy); cmac(yb, xo[hp][2 * p], wc[p].xy);
-            cmac(ya, xe[hp][2 * p + 1], wc[p].zw); cmac(yb, xo[hp][2 * p + 1], wc[p].zw);
+            // (ya += xe_a h_a + xe_b h_b ; yb += xo_a h_a + xo_b h_b: two chains, interleaved)
+            asm("v_pk_fma_f32 %0, %2, %6, %0 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %1, %4, %6, %1 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %0, %2, %6, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %1, %4, %6, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %0, %3, %7, %0 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %1, %5, %7, %1 op_sel_hi:[0,1,1]\n\t"
+                "v_pk_fma_f32 %0, %3, %7, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+                "v_pk_fma_f32 %1, %5, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+                : "+v"(ya), "+v"(yb)
+                : "v"(xe[hp][2 * p]), "v"(xe[hp][2 * p + 1]), "v"(xo[hp][2 * p]), "v"(xo[hp][2 * p + 1]), "v"(wc[p].xy), "v"(wc[p].zw));
           }
           if (f != 0) {
             f2* zb = zbuf + (hp * 8 + o) * G::LSEQ;
@@ -412,6 +434,11 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     auto issue = [&](int m, int q, f4 (&dst)[2 * NPI]) {
       const unsigned vo = (unsigned)(tid + m * NT) * 16u;
       const unsigned sa = wbase + (unsigned)(2 * q) * ostride, sb = sa + ostride;
+#if FC_DIAG == 1
+#pragma unroll
+      for (int p = 0; p < 2 * NPI; ++p) { f4 c; c.x = 1e-3f * (p + q); c.y = c.x; c.z = c.x; c.w = c.x; asm volatile("" : "+v"(c)); dst[p] = c; }
+      return;
+#endif
 #pragma unroll
       for (int p = 0; p < NPI; ++p) {
         dst[2 * p] = buf_load_f32x4(wg, vo, sa + p * (T / 2) * 16);
@@ -426,7 +453,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
       if constexpr (s < BP * NPI) issue(s / NPI, s % NPI, wr[s]);
     });
     stampi(it, 4);
+#if FC_DIAG != 5
     __syncthreads();
+#endif
     stampi(it, 5);
     {
       f2 sbz[NPI];
@@ -442,8 +471,7 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
 #pragma unroll
           for (int p = 0; p < NPI; ++p) {
             const f4 ha = wc[2 * p], hb = wc[2 * p + 1];
-            cmac(ya, xe[b][p], ha.xy); cmac(ya, xo[b][p], ha.zw);
-            cmac(yb, xe[b][p], hb.xy); cmac(yb, xo[b][p], hb.zw);
+            cmac2x2(ya, yb, xe[b][p], xo[b][p], ha.xy, ha.zw, hb.xy, hb.zw);
           }
           if (f != 0 && b < wi.nbc) {
             f2* zb = zbuf + (b * NPI + q) * G::LSEQ;
@@ -499,7 +527,9 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
     }
     }   // dense / depthwise mix
     stampi(it, 6);
+#if FC_DIAG != 5
     __syncthreads();
+#endif
     stampi(it, 7);
     // gfx9 counts loads and stores in ONE vmcnt: a value first used after later memory instructions went out through
     // branches gets a full s_waitcnt vmcnt(0).  The bias is therefore declared arrived here (only this item's spectrum
@@ -562,11 +592,17 @@ __global__ __launch_bounds__(NT, 2) void conv1d_pers_kernel(const Conv1dPersArgs
         static_for<0, P / 8>([&](auto bc) {
           constexpr int k0 = 8 * decltype(bc)::value;
           if (ka >= k0 + 8) {
+#if FC_DIAG == 6
+            { f2 sink = v[k0];
+              static_for<k0 + 1, k0 + 8>([&](auto kc) { sink += v[decltype(kc)::value]; });
+              if (sink.x == 123.456f) buf_store_f32(sink.x + bias0 + bias1, yr, vo0, 0); }
+#else
             static_for<k0, k0 + 8>([&](auto kc) {
               constexpr int k = decltype(kc)::value;
               buf_store_f32(v[k].x + bias0, yr, vo0, P * k * 4);
               buf_store_f32(v[k].y + bias1, yr, vo1, P * k * 4);
             });
+#endif
           } else if (ka >= k0) {
             static_for<k0, k0 + 8>([&](auto kc) {
               constexpr int k = decltype(kc)::value;

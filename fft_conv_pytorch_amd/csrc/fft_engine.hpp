@@ -20,6 +20,10 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#ifndef FC_DIAG
+#define FC_DIAG 0     // diagnostic builds (scripts/experiments/exp_cfgA_diag.sh): 2 = no LDS stores in the transform passes of the
+#endif                // batch-sharing kernel, 3 = no twiddle-table reads; timing only, the results are wrong
+
 namespace fc {
 
 // One complex value = one 64-bit VGPR pair.  gfx950 issues a wave64 VALU instruction in 4 cycles
@@ -54,20 +58,35 @@ __device__ __forceinline__ f2 conj_add_iconj(f2 a, f2 b) {
 // x * w and x * conj(w), w = (cos, sin) in registers
 __device__ __forceinline__ f2 cmul(f2 x, f2 w) {
   f2 t;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(w), "v"(x));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(t) : "v"(w), "v"(x));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=&v"(t) : "v"(w), "v"(x));
   return t;
 }
 __device__ __forceinline__ f2 cmulc(f2 x, f2 w) {
   f2 t;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(w), "v"(x));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "+v"(t) : "v"(w), "v"(x));
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=&v"(t) : "v"(w), "v"(x));
   return t;
 }
-// y += x * h  (complex multiply-accumulate, 2 instructions)
+// y += x * h  (complex multiply-accumulate, 2 instructions in ONE asm statement: between two asm statements that
+// depend on each other hipcc puts an s_nop -- 250 of them in a cfgA mix of 576 instructions)
 __device__ __forceinline__ void cmac(f2& y, f2 x, f2 h) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(y) : "v"(x), "v"(h));
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(y) : "v"(x), "v"(h));
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(y) : "v"(x), "v"(h));
+}
+// ya += xa * ha + xb * hb ; yb += xa * ga + xb * gb, the two accumulation chains interleaved: a dependent v_pk_fma_f32
+// issues every 8 cycles, two independent ones every 4 -- written as consecutive cmac() calls the compiler kept every
+// chain back to back (the mix of one work item: ~4k instead of ~2k cycles of a wave's own time)
+__device__ __forceinline__ void cmac2x2(f2& ya, f2& yb, f2 xa, f2 xb, f2 ha, f2 hb, f2 ga, f2 gb) {
+  asm("v_pk_fma_f32 %0, %2, %4, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %2, %6, %1 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %2, %4, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %2, %6, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %0, %3, %5, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %1, %3, %7, %1 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %3, %5, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %1, %3, %7, %1 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+v"(ya), "+v"(yb) : "v"(xa), "v"(xb), "v"(ha), "v"(hb), "v"(ga), "v"(gb));
 }
 // x * (c + i*s) with compile-time c, s (hipcc folds the modifiers itself)
 __device__ __forceinline__ f2 cmul_const(f2 x, float c, float s) {
@@ -161,6 +180,13 @@ struct NoHook {
 };
 template <int P, int DIR, class H = NoHook>
 __device__ __forceinline__ void fft_regs(f2 (&v)[P], H&& hook = H{}) {
+#if FC_DIAG == 8
+  if constexpr (P == 32) {          // timing experiment: the 32-point register transforms do nothing
+#pragma unroll
+    for (int i = 0; i < P; ++i) asm volatile("" : "+v"(v[i]));
+    return;
+  }
+#endif
   constexpr int LG = ilog2(P);
   f2 t[P];
 #pragma unroll
@@ -335,11 +361,23 @@ __device__ __forceinline__ void passA_fft_twiddle_store_lds(f2 (&v)[G::P], f2* _
                                                             const f2* __restrict__ twl, H&& hook = H{}) {
   fft_regs<G::P, DIR>(v, hook);
   f2 w[G::P];
+#if FC_DIAG == 3 || FC_DIAG == 4
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) { w[k1] = mk2(1.f, 1e-3f * k1); asm volatile("" : "+v"(w[k1])); }
+#else
   lds_read_strided<G::P, G::N2, 1>(w, twl + n2);
   lds_arrive<G::P, 1>(w);
+#endif
+#if FC_DIAG == 2
+  f2 sink = v[0];
+#pragma unroll
+  for (int k1 = 1; k1 < G::P; ++k1) sink += (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
+  if (sink.x == 123.456f) lseq[n2] = sink;          // (keeps the arithmetic alive, never stores)
+#else
   lseq[n2] = v[0];
 #pragma unroll
   for (int k1 = 1; k1 < G::P; ++k1) lseq[k1 * G::RS + n2] = (DIR > 0) ? cmulc(v[k1], w[k1]) : cmul(v[k1], w[k1]);
+#endif
 }
 
 // same, with the table read in two halves (half the twiddle registers live at a time): for kernels that
@@ -371,18 +409,30 @@ __device__ __forceinline__ void passA_fft_twiddle_store_lds_lowreg(f2 (&v)[G::P]
 template <class G>
 __device__ __forceinline__ void passB_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {
   const int k1 = tseq >> G::LGS, r = tseq & (G::S - 1);
+#if FC_DIAG == 4
+#pragma unroll
+  for (int i = 0; i < G::P; ++i) asm volatile("" : "+v"(v[i]));
+  (void)k1; (void)r; (void)lseq;
+#else
   lds_read_strided<G::P, G::S>(v, lseq + k1 * G::RS + r);
   lds_arrive(v);
+#endif
 }
 // Inverse pass-A load from the natural layout: v[i1] = Z[N2*i1 + tseq]
 template <class G>
 __device__ __forceinline__ void nat_load(f2 (&v)[G::P], const f2* __restrict__ lseq, int tseq) {
   const unsigned addr = lds_off(lseq + tseq);
+#if FC_DIAG == 4
+#pragma unroll
+  for (int i = 0; i < G::P; ++i) { v[i] = mk2(1e-3f * i, 1.f); asm volatile("" : "+v"(v[i])); }
+  (void)addr;
+#else
   static_for<0, G::P>([&](auto ic) {
     constexpr int i1 = decltype(ic)::value;
     v[i1] = lds_rd<(G::N2 * i1 + G::NATPAD * (i1 / (G::P / G::S))) * 8>(addr);
   });
   lds_arrive(v);
+#endif
 }
 
 // Pass-B compute: register FFT + lane-split finish.  Returns j such that element

@@ -74,13 +74,27 @@ __global__ __launch_bounds__(kPlNT) void planes_fwd_kernel(const PlaneFwdArgs a)
   {
     const float* plane = a.src + ((size_t)img * a.SZ + zs) * a.SY * a.SX;
     const BufRsrc pr = make_rsrc(plane, (unsigned)(a.SY * a.SX * 4));
-    const int xp = tid & 63, xs = axis_src(a.mx, xp);
+    const int xp = tid & 63;
     float val[16];
+    if (a.mx.up == 1 && a.my.up == 1 && a.mx.mode == PAD_CONSTANT) {
+      // zero padding, no spread (the usual case): a shift and a bounds test per element -- the general index map below is
+      // a division and three mode branches per element, 17 times per thread: most of this kernel's instructions
+      const int xs = xp - a.mx.pad;
+      const bool xok = (unsigned)xs < (unsigned)a.SX;
+      const unsigned base = (unsigned)(((tid >> 6) - a.my.pad) * a.SX + xs) * 4u, step = (unsigned)(4 * a.SX) * 4u;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int yp = (tid >> 6) + 4 * u;
-      const int ys = axis_src(a.my, yp);
-      val[u] = buf_load_f32(pr, (ys >= 0 && xs >= 0) ? (unsigned)(ys * a.SX + xs) * 4u : 0xFFFFFFFFu, 0);
+      for (int u = 0; u < 16; ++u) {
+        const int ys = (tid >> 6) + 4 * u - a.my.pad;
+        val[u] = buf_load_f32(pr, (xok && (unsigned)ys < (unsigned)a.SY) ? base + step * u : 0xFFFFFFFFu, 0);
+      }
+    } else {
+      const int xs = axis_src(a.mx, xp);
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int yp = (tid >> 6) + 4 * u;
+        const int ys = axis_src(a.my, yp);
+        val[u] = buf_load_f32(pr, (ys >= 0 && xs >= 0) ? (unsigned)(ys * a.SX + xs) * 4u : 0xFFFFFFFFu, 0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 16; ++u) rowbuf[((tid >> 6) + 4 * u) * RP + xp] = val[u];
@@ -194,10 +208,18 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
   passB_load<G>(v, seq, tseq);
   passB_compute<G, +1>(v, tseq, twB);
   __syncthreads();                                         // every column is in registers
+  if (a.sy == 1) {                                          // (no emulated division per sample)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int n = tseq + 8 * k, yo = n / a.sy;
-    if (n < a.NVy && yo * a.sy == n) reg[yo * YP + sq] = v[k];
+    for (int k = 0; k < 8; ++k) {
+      const int n = tseq + 8 * k;
+      if (n < a.NVy) reg[n * YP + sq] = v[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int n = tseq + 8 * k, yo = n / a.sy;
+      if (n < a.NVy && yo * a.sy == n) reg[yo * YP + sq] = v[k];
+    }
   }
   __syncthreads();
   // ---- x rows back: output rows 2sq (-> real part) and 2sq+1 (-> imaginary part) share one inverse transform
@@ -230,12 +252,23 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
   }
   __syncthreads();                                          // every exchange has been read: the region becomes the output plane
   float* ob = reinterpret_cast<float*>(reg);                // [Yo][Xo]
+  if (a.sx == 1) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int n = tseq + 8 * k, xo = n / a.sx;
-    if (n < a.NVx && xo * a.sx == n) {
-      if (has_a) ob[ra * a.Xo + xo] = v[k].x + b;
-      if (has_b) ob[rb * a.Xo + xo] = v[k].y + b;
+    for (int k = 0; k < 8; ++k) {
+      const int n = tseq + 8 * k;
+      if (n < a.NVx) {
+        if (has_a) ob[ra * a.Xo + n] = v[k].x + b;
+        if (has_b) ob[rb * a.Xo + n] = v[k].y + b;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int n = tseq + 8 * k, xo = n / a.sx;
+      if (n < a.NVx && xo * a.sx == n) {
+        if (has_a) ob[ra * a.Xo + xo] = v[k].x + b;
+        if (has_b) ob[rb * a.Xo + xo] = v[k].y + b;
+      }
     }
   }
   __syncthreads();

@@ -17,13 +17,13 @@ LIB_PATH = os.environ.get("FFTCONV_LIB") or os.path.join(_HERE, LIB_NAME)   # en
 
 FC_OK, FC_ERR_INVALID, FC_ERR_UNSUPPORTED, FC_ERR_HIP = 0, 1, 2, 3
 PAD_MODES = {"constant": 0, "zeros": 0, "reflect": 1, "replicate": 2, "circular": 3}
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 EXPORTS = (
     "fc_version", "fc_last_error", "fc_plan_create", "fc_plan_destroy", "fc_output_shape",
     "fc_kernel_spectrum_bytes", "fc_workspace_bytes", "fc_plan_tile", "fc_plan_layout", "fc_transform_kernel",
     "fc_forward", "fc_forward_stamped", "fc_wgrad1d_slices", "fc_wgrad1d", "fc_wgrad1d_db", "fc_wgrad1d_db_supported",
-    "fc_debug_grid",
+    "fc_debug_grid", "fc_wgrad_nd_plan_create", "fc_wgrad_nd",
 )
 
 
@@ -89,6 +89,10 @@ def load_library() -> ctypes.CDLL:
         lib.fc_wgrad1d_db.restype = i32
         lib.fc_wgrad1d_db_supported.argtypes = [ctypes.POINTER(FcDesc)]
         lib.fc_wgrad1d_db_supported.restype = i32
+        lib.fc_wgrad_nd_plan_create.argtypes = [ctypes.POINTER(FcDesc), ctypes.POINTER(vp)]
+        lib.fc_wgrad_nd_plan_create.restype = i32
+        lib.fc_wgrad_nd.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        lib.fc_wgrad_nd.restype = i32
         lib.fc_forward_stamped.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         lib.fc_forward_stamped.restype = i32
         lib.fc_plan_layout.argtypes = [vp, ctypes.POINTER(ctypes.c_int32 * 8)]
@@ -140,6 +144,35 @@ def wgrad1d_db(desc: FcDesc, x_ptr: int, dy_ptr: int, partial_ptr: int, db_ptr: 
     st = lib.fc_wgrad1d_db(ctypes.byref(desc), x_ptr, dy_ptr, partial_ptr, db_ptr, slice_stride, slices, stream)
     if st != FC_OK:
         _raise(lib, st)
+
+
+class WgradPlan:
+    """Owns the plan of ``fc_wgrad_nd`` for one convolution descriptor (2-D / 3-D, float32): created on the CURRENT HIP
+    device.  ``run`` reads x (B, Cin, *S) and dY (B, Cout, *Lout) and writes dW (Cout, Cin/g, *k) -- no copies around it."""
+
+    def __init__(self, desc: FcDesc):
+        lib = load_library()
+        handle = ctypes.c_void_p()
+        st = lib.fc_wgrad_nd_plan_create(ctypes.byref(desc), ctypes.byref(handle))
+        if st != FC_OK:
+            _raise(lib, st)
+        self._lib, self._h = lib, handle
+        self.spectrum_bytes = int(lib.fc_kernel_spectrum_bytes(handle))
+        self.workspace_bytes = int(lib.fc_workspace_bytes(handle))
+        self.tile = int(lib.fc_plan_tile(handle))
+
+    def run(self, x_ptr: int, dy_ptr: int, dw_ptr: int, spectrum_ptr: int, workspace_ptr: Optional[int], stream: int):
+        st = self._lib.fc_wgrad_nd(self._h, x_ptr, dy_ptr, dw_ptr, spectrum_ptr, workspace_ptr, stream)
+        if st != FC_OK:
+            _raise(self._lib, st)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.fc_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
 
 def _raise(lib, status: int):

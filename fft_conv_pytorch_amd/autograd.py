@@ -5,8 +5,10 @@ The reference has no custom backward: autograd differentiates its rfftn/einsum/i
 autograd, so the three gradients are expressed as convolutions the native library already runs:
 
     dX = conv_transpose(dY, W)             -> ``fc_forward`` on a transposed plan
-    dW = correlate(X, dY) over the batch   -> 1-D, stride 1, <= 64 channels per group: ``fc_wgrad1d`` (cross-spectra
-                                              accumulated on chip); otherwise ``fc_forward`` with the roles of
+    dW = correlate(X, dY) over the batch   -> 1-D, <= 64 channels per group: ``fc_wgrad1d`` (cross-spectra
+                                              accumulated on chip); 2-D / 3-D: ``fc_wgrad_nd`` (the role-swapped
+                                              convolution below, run by the library on the tensors as they lie);
+                                              otherwise ``fc_forward`` with the roles of
                                               batch and channels swapped: signal' = X^T (Cin/g, B, *S), kernel' =
                                               dY^T (Cout/g, B, *Lout), dilation' = stride, stride' = dilation;
                                               all channel groups ride the group axis of that one call, long 1-D
@@ -179,10 +181,49 @@ def _grad_weight_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilati
     return total[:n_w].view(wshape), (total[n_w:] if with_db else None)
 
 
+def _grad_weight_nd_native(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode):
+    """2-D / 3-D dW by ``fc_wgrad_nd``: the role-swapped convolution run by the library on the tensors as they are
+    (x (B, Cin, *S) and dY (B, Cout, *Lout) are read, dW (Cout, Cin/g, *k) is written, in these layouts) -- no transposed
+    copies, no crop, no reduction on the torch side.  None when not covered (1-D, float64, a shape the plan refuses)."""
+    n = x.ndim - 2
+    if n < 2 or x.dtype != torch.float32:
+        return None
+    from . import _native
+    if grad.device != x.device:
+        raise ValueError(f"gradient is on {grad.device} but the signal is on {x.device}")
+    key = ("dwn", tuple(x.shape), tuple(wshape), stride, padding, dilation, groups, padding_mode, x.device)
+    plan = _BWD_PLANS.get(key)
+    if plan is None:
+        desc = _native.conv_desc(n, x.shape[0], x.shape[1], wshape[0], groups, tuple(x.shape[2:]), tuple(wshape[2:]), stride,
+                                 padding, dilation, _native.PAD_MODES[padding_mode])
+        try:
+            with torch.cuda.device(x.device):
+                plan = _native.WgradPlan(desc)
+        except NotImplementedError:
+            plan = False                      # (remembered: the forward-plan route below takes this shape)
+        if len(_BWD_PLANS) > 256:
+            _BWD_PLANS.clear()
+        _BWD_PLANS[key] = plan
+    if plan is False:
+        return None
+    x = x.contiguous()
+    grad = grad.contiguous()
+    with torch.cuda.device(x.device):
+        dw = torch.empty(tuple(wshape), device=x.device, dtype=torch.float32)
+        spec = torch.empty(plan.spectrum_bytes, device=x.device, dtype=torch.uint8)
+        ws = torch.empty(max(plan.workspace_bytes, 1), device=x.device, dtype=torch.uint8)
+        plan.run(x.data_ptr(), grad.data_ptr(), dw.data_ptr(), spec.data_ptr(), ws.data_ptr(),
+                 torch.cuda.current_stream(x.device).cuda_stream)
+    return dw
+
+
 def _grad_weight(x: Tensor, grad: Tensor, wshape, stride, padding, dilation, groups, padding_mode) -> Tensor:
     native = _grad_weight_native(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
     if native is not None:
         return native[0]
+    nd = _grad_weight_nd_native(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
+    if nd is not None:
+        return nd
     return _grad_weight_plans(x, grad, wshape, stride, padding, dilation, groups, padding_mode)
 
 
@@ -215,8 +256,11 @@ class FFTConvFunction(torch.autograd.Function):
             if native is not None:
                 d_kernel, d_bias = native          # (db rode the weight-gradient launch where the kernel offers it)
             else:
-                d_kernel = _grad_weight_plans(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation,
-                                              groups, padding_mode)
+                d_kernel = _grad_weight_nd_native(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation,
+                                                  groups, padding_mode)
+                if d_kernel is None:
+                    d_kernel = _grad_weight_plans(signal.detach(), grad, tuple(kernel.shape), stride, padding, dilation,
+                                                  groups, padding_mode)
         if want_db and d_bias is None:
             d_bias = grad.sum(dim=[0] + list(range(2, grad.ndim)))
         return d_signal, d_kernel, d_bias, None, None, None, None, None, None

@@ -192,6 +192,15 @@ struct fc_plan {
   int ph;                     // dilation run as this many phases of a virtual batch (batch-sharing kernel), else 1
   int ph2;                    // the phases run in pairs (conv1d_pers.hpp PH2)
   fc::WorkItem* d_items;
+  // ---- weight-gradient plan of an N-d convolution (fc_wgrad_nd): the convolution with batch and channels exchanged;
+  // the tensors keep the caller's layout (ImgMap in the row passes)
+  int swap;
+  int64_t sw_B, sw_Cig, sw_Cog, sw_g;      // of the ORIGINAL convolution
+};
+
+// the original convolution behind a weight-gradient plan: batch, channels per group, groups, taps to keep per axis
+struct WgradSwap {
+  int64_t B, Cig, Cog, g, keep[3];
 };
 
 extern "C" {
@@ -683,7 +692,7 @@ static int plan_nd(fc_plan* p) {
   {
     const char* env = getenv("FFTCONV_PLANES");
     const fc::TileImpl* t64 = find_tile(64);
-    planes_ok = (!env || atoi(env) != 0) && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 && p->nxt == 1 &&
+    planes_ok = (!env || atoi(env) != 0) && !p->swap && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 && p->nxt == 1 &&
                 p->nyt == 1 && p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) &&
                 (int64_t)2 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) < 65536;   // (32-bit offsets below 2 GiB per workgroup)
   }
@@ -753,7 +762,11 @@ static int plan_nd(fc_plan* p) {
   return rc;
 }
 
-int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
+static int plan_create_impl(const fc_desc* desc, const WgradSwap* sw, fc_plan** out_plan);
+
+int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) { return plan_create_impl(desc, nullptr, out_plan); }
+
+static int plan_create_impl(const fc_desc* desc, const WgradSwap* sw, fc_plan** out_plan) {
   if (!desc || !out_plan) return fail(FC_ERR_INVALID, "null argument");
   (void)hipGetLastError();   // a stale sticky error of an earlier, unrelated call (e.g. an invalidated capture) is not this call's
   *out_plan = nullptr;
@@ -771,6 +784,7 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
   std::memset(p, 0, sizeof *p);
   p->d = d;
   p->nd = d.ndim;
+  if (sw) { p->swap = 1; p->sw_B = sw->B; p->sw_Cig = sw->Cig; p->sw_Cog = sw->Cog; p->sw_g = sw->g; }
   if (d.transposed && d.padding_mode != FC_PAD_CONSTANT) {
     delete p;
     return fail(FC_ERR_INVALID, "a transposed plan supports zero padding only");
@@ -809,6 +823,13 @@ int fc_plan_create(const fc_desc* desc, fc_plan** out_plan) {
     p->ostride[i] = (int)d.stride[i];
     p->Sp[i] = (int)(d.spatial[i] + 2 * d.padding[i]);
     p->Lf[i] = (int)(span + 1);
+    if (sw && p->out_sp[i] > sw->keep[i]) {
+      // weight gradient: only the first k lags are taps of dW (the input samples a strided convolution never reached
+      // would give more); the passes then read no further than those lags need
+      p->out_sp[i] = sw->keep[i];
+      p->Lf[i] = (int)((sw->keep[i] - 1) * d.stride[i] + 1);
+      p->Sp[i] = (int)(p->Lf[i] + p->kd[i] - 1);
+    }
     if (d.padding_mode == FC_PAD_REFLECT && d.padding[i] >= d.spatial[i]) {
       delete p;
       return fail(FC_ERR_INVALID, "axis %d: reflect padding (%lld) must be smaller than the input size (%lld)", i,
@@ -885,15 +906,16 @@ struct WgradGeom {
   int kd_seg, seg_taps, nseg, V, ntiles, nob, nib, Cig, Cog, n_items, ipw, slices, pad, diag;
 };
 int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
-  if (d.ndim != 1 || d.dtype != FC_F32 || d.transposed || d.stride[0] != 1 || d.groups < 1) return 0;
+  if (d.ndim != 1 || d.dtype != FC_F32 || d.transposed || d.stride[0] < 1 || d.stride[0] > 64 || d.groups < 1) return 0;
   if (d.batch < 1 || d.in_channels % d.groups || d.out_channels % d.groups) return 0;
   const int64_t Cig = d.in_channels / d.groups, Cog = d.out_channels / d.groups;
   if (Cig > 64 || Cog > 64) return 0;      // every 4 x 4 channel block repeats the transforms of its rows: beyond this the plan path wins
   const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
   const fc::TileImpl* t = find_tile(1024);
   if (!t || !t->wgrad1d || d.padding[0] < 0 || d.dilation[0] > 512) return 0;
-  const int64_t Lout = d.spatial[0] + 2 * d.padding[0] - kd + 1;
-  if (Lout < 1) return 0;
+  if (d.spatial[0] + 2 * d.padding[0] - kd < 0) return 0;
+  const int64_t Lout = (d.spatial[0] + 2 * d.padding[0] - kd) / d.stride[0] + 1;
+  const int64_t Lext = (Lout - 1) * d.stride[0] + 1;       // the gradient row spread over the stride's grid
   if (d.padding_mode == FC_PAD_REFLECT && d.padding[0] >= d.spatial[0]) return 0;
   if (d.padding_mode == FC_PAD_CIRCULAR && d.padding[0] > d.spatial[0]) return 0;
   if ((int64_t)d.batch * d.in_channels * d.spatial[0] * 4 >= ((int64_t)1 << 32) ||
@@ -903,7 +925,9 @@ int wgrad_geometry(const fc_desc& d, WgradGeom* g) {
   const int64_t kd_seg = (ks - 1) * d.dilation[0] + 1;
   const int64_t nseg = (d.kernel[0] + ks - 1) / ks;
   if (nseg > 64) return 0;
-  const int64_t V = t->T - kd_seg + 1, ntiles = (Lout + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
+  const int64_t V = (t->T - kd_seg + 1) / d.stride[0] * d.stride[0];      // tiles start on the stride's grid
+  if (V < 1) return 0;
+  const int64_t ntiles = (Lext + V - 1) / V, n_items = (int64_t)d.batch * ntiles;
   if (n_items > 0x3fffffff) return 0;
   int cus = 256;
   if (!current_device_cus(&cus)) return 0;
@@ -971,7 +995,8 @@ int fc_wgrad1d_db(const fc_desc* desc, const float* x, const float* dy, float* p
   a.G = g.diag ? (int)(d.groups / 8) : (int)d.groups;
   a.Cig = g.Cig; a.Cog = g.Cog; a.L = (int)d.spatial[0]; a.pad = g.pad; a.pad_mode = d.padding_mode;
   const int64_t kd = (d.kernel[0] - 1) * d.dilation[0] + 1;
-  a.Lout = (int)(d.spatial[0] + 2 * d.padding[0] - kd + 1);
+  a.Lout = (int)((d.spatial[0] + 2 * d.padding[0] - kd) / d.stride[0] + 1);
+  a.stride = (int)d.stride[0]; a.Lext = (a.Lout - 1) * a.stride + 1;
   a.dil = (int)d.dilation[0]; a.V = g.V; a.ntiles = g.ntiles;
   a.n_items = g.n_items; a.items_per_slice = g.ipw; a.nob = g.nob; a.nib = g.nib;
   a.scale = 1.0f / (4.0f * (float)g.t->T);
@@ -1099,6 +1124,16 @@ int fc_transform_kernel(const fc_plan* plan, const float* weight, void* w_hat, v
   r.SZ = r.kz; r.SY = r.ky; r.SX = r.kx; r.Fx = p.Fx;
   r.nxt = 1; r.Vx = 0;                       // the kernel sits in the first x tile
   r.transposed = p.d.transposed; r.Cig = p.Cig; r.Cog = p.Cog;
+  if (p.swap) {   // "kernel" = the output gradient (B, g*Cog, *Lout), read as ((g, o), b): image o_all*B + b sits at b*(g*Cog) + o_all
+    r.im.on = 1; r.im.n1 = 1; r.im.n2 = (int)p.sw_B; r.im.s0 = 1; r.im.s1 = 0; r.im.s2 = p.sw_g * p.sw_Cog;
+    // a tensor as large as the signal: read it through the signal's index maps (taps spread by the dilation = a source
+    // spread over a grid of that step, nothing in front), which have the unrolled zero-padding path the tap loop lacks
+    r.from_kernel = 0;
+    auto tmap = [&](int64_t taps, int64_t dil) { fc::AxisMap m; m.size = (int)taps; m.pad = 0; m.mode = FC_PAD_CONSTANT; m.up = (int)dil; return m; };
+    r.mx = tmap(r.kx, r.dx); r.my = tmap(r.ky, r.dy); r.mz = tmap(r.kz, r.dz);
+    const unsigned long long bytes = 4ull * (unsigned long long)r.NA * r.SZ * r.SY * r.SX;
+    r.src_bytes = bytes < 0xFFFFFFFFull ? (unsigned)bytes : 0u;
+  }
   FC_HIP(p.tx->rows_r2c(r, st));
   const float norm = 1.0f / ((float)p.tx->T * (float)p.tile->T * (nd == 3 ? (float)p.tm->T : 1.0f));
   fc::C2CArgs c{};
@@ -1277,6 +1312,9 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     const unsigned long long bytes = 4ull * (unsigned long long)B * Ci * r.SZ * r.SY * r.SX;
     r.src_bytes = bytes < 0xFFFFFFFFull ? (unsigned)bytes : 0u;
   }
+  if (p.swap) {   // signal = x (B, g*Cig, *S) read as (i, (g, b)): image (i*g + gi)*B + b sits at b*(g*Cig) + gi*Cig + i
+    r.im.on = 1; r.im.n1 = (int)p.sw_g; r.im.n2 = (int)p.sw_B; r.im.s0 = 1; r.im.s1 = p.sw_Cig; r.im.s2 = p.sw_g * p.sw_Cig;
+  }
   FC_HIP(p.tx->rows_r2c(r, st));
 
   fc::FusedCArgs f{};
@@ -1293,6 +1331,9 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   f.wfx = p.Fx; f.wty = nd == 3 ? p.tm->T : 1; f.wrep = nd == 3 ? p.nyt : 1; f.wncol = f.wfx * f.wty;
   o.NV = p.Lf[nd - 1]; o.stride = p.ostride[nd - 1]; o.Xo = (int)p.out_sp[nd - 1];
   o.NY = (int)p.out_sp[nd - 2]; o.NYa = o.NY;
+  if (p.swap) {   // output (i, (g, o), *k) written as dW ((g, o), i, *k): image i*(g*Cog) + o_all goes to o_all*Cig + i
+    o.im.on = 1; o.im.n1 = 1; o.im.n2 = (int)(p.sw_g * p.sw_Cog); o.im.s0 = 1; o.im.s1 = 0; o.im.s2 = p.sw_Cig;
+  }
 
   if (nd == 2) {
     f.src = wsA; f.dst = wsB; f.ncol = Fs;
@@ -1331,6 +1372,47 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     FC_HIP(p.tx->rows_c2r(o, st));
   }
   return FC_OK;
+}
+
+// ---- N-d weight gradient (the reference's dW comes from autograd through its
+// rfftn / einsum / irfftn graph, tests/test_functional.py:111-117): dW[(g,o)][i][k] = sum_b sum_t dY[b][(g,o)][t] *
+// Xp[b][(g,i)][t*s + k*d] is the convolution of signal' = X with batch and channels exchanged against kernel' = dY,
+// stride' = dilation, dilation' = stride, of which the first k lags per axis are kept.  The plan is that convolution;
+// both tensors are read, and dW written, in the caller's layout (ImgMap) -- no transposed copies, no crop afterwards.
+int fc_wgrad_nd_plan_create(const fc_desc* conv, fc_plan** out_plan) {
+  if (!conv || !out_plan) return fail(FC_ERR_INVALID, "null argument");
+  *out_plan = nullptr;
+  const fc_desc& c = *conv;
+  if (c.ndim < 2 || c.ndim > 3) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad_nd covers 2-D and 3-D convolutions (1-D: fc_wgrad1d)");
+  if (c.dtype != FC_F32 || c.transposed) return fail(FC_ERR_UNSUPPORTED, "fc_wgrad_nd: float32, not transposed");
+  if (c.batch < 1 || c.in_channels < 1 || c.out_channels < 1 || c.groups < 1 || c.in_channels % c.groups || c.out_channels % c.groups)
+    return fail(FC_ERR_INVALID, "batch, channels and groups must be positive and the channels divisible by groups");
+  WgradSwap sw;
+  sw.B = c.batch; sw.g = c.groups; sw.Cig = c.in_channels / c.groups; sw.Cog = c.out_channels / c.groups;
+  fc_desc d = c;
+  d.batch = sw.Cig; d.in_channels = sw.g * sw.B; d.out_channels = sw.g * sw.Cog; d.groups = sw.g;
+  d.has_bias = 0; d.tile_hint = 0;
+  for (int i = 0; i < 3; ++i) sw.keep[i] = 1;
+  for (int i = 0; i < c.ndim; ++i) {
+    if (c.spatial[i] < 1 || c.kernel[i] < 1 || c.stride[i] < 1 || c.dilation[i] < 1 || c.padding[i] < 0)
+      return fail(FC_ERR_INVALID, "axis %d: spatial/kernel/stride/dilation must be >= 1 and padding >= 0", i);
+    const int64_t kd = (c.kernel[i] - 1) * c.dilation[i] + 1;
+    const int64_t span = c.spatial[i] + 2 * c.padding[i] - kd;
+    if (span < 0) return fail(FC_ERR_INVALID, "axis %d: dilated kernel extent %lld is larger than the padded input", i, (long long)kd);
+    d.kernel[i] = span / c.stride[i] + 1;          // taps of kernel' = output extent of the convolution
+    d.stride[i] = c.dilation[i];
+    d.dilation[i] = c.stride[i];
+    sw.keep[i] = c.kernel[i];
+  }
+  return plan_create_impl(&d, &sw, out_plan);
+}
+
+int fc_wgrad_nd(const fc_plan* plan, const float* x, const float* dy, float* dw, void* spectrum, void* workspace, void* hip_stream) {
+  if (!plan || !x || !dy || !dw || !spectrum) return fail(FC_ERR_INVALID, "null argument");
+  if (!plan->swap) return fail(FC_ERR_INVALID, "not a weight-gradient plan (fc_wgrad_nd_plan_create)");
+  int rc = fc_transform_kernel(plan, dy, spectrum, workspace, hip_stream);
+  if (rc != FC_OK) return rc;
+  return fc_forward(plan, x, spectrum, nullptr, dw, workspace, hip_stream);
 }
 
 }  // extern "C"

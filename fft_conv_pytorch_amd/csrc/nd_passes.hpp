@@ -39,6 +39,18 @@ __device__ __forceinline__ int axis_src(const AxisMap& m, int p) {   // p: padde
   if (m.mode == PAD_REPLICATE) return pos < 0 ? 0 : m.size - 1;
   return pos < 0 ? pos + m.size : pos - m.size;
 }
+// Image index as the pass counts it -> image index in the caller's tensor.  Off (identity) for a convolution; the
+// weight-gradient plans (fc_wgrad_nd) read the signal and the output gradient with batch and channels exchanged
+// and write dW in the weight layout, without a transposed copy:  img = (q0*n1 + q1)*n2 + q2  ->  q0*s0 + q1*s1 + q2*s2.
+struct ImgMap {
+  int on, n1, n2;
+  long long s0, s1, s2;
+};
+__device__ __forceinline__ size_t map_img(const ImgMap& m, int img) {
+  if (!m.on) return (size_t)img;
+  const int q2 = img % m.n2, t = img / m.n2;
+  return (size_t)((long long)(t / m.n1) * m.s0 + (long long)(t % m.n1) * m.s1 + (long long)q2 * m.s2);
+}
 // Kernel taps: position p -> tap index p/dil if p is a multiple of dil and in range.
 __device__ __forceinline__ int tap_src(int p, int dil, int k) {
   const int t = p / dil;
@@ -127,6 +139,7 @@ struct RowsR2CArgs {
   unsigned src_bytes;    // size of the source tensor when it fits 32-bit buffer offsets, else 0
   int nxt, Vx;           // overlap-save tiles along x (rows longer than the largest FFT): tile xt holds the padded
                          // positions [xt*Vx, xt*Vx + T); dst has nxt*Fx bin columns per plane (1, - for one tile)
+  ImgMap im;             // where image `img` of this pass sits in src (identity unless a weight-gradient plan)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
         zs = axis_src(a.mz, c);       // (2-D plans carry an identity map here)
       }
       ok[h] = ys >= 0 && zs >= 0;
-      size_t simg = img;
+      size_t simg = map_img(a.im, img);
       if (a.from_kernel && a.transposed) {
         const int o_all = img / a.Cig, i = img % a.Cig;
         simg = (size_t)((o_all / a.Cog) * a.Cig + i) * a.Cog + (o_all % a.Cog);
@@ -407,6 +420,7 @@ struct RowsC2RArgs {
   int NA, NC, NY, NYa, Fx, Cout;
   int NV, stride, Xo;    // valid stride-1 samples along x, decimation, output row length
   int nxt, Vx;           // x tiles (see RowsR2CArgs): tile xt yields the stride-1 samples [xt*Vx, xt*Vx + Vx)
+  ImgMap im;             // where image `img` of this pass goes in dst (identity unless a weight-gradient plan)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -502,7 +516,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   asm volatile("" : "+v"(b));
   // buffer stores relative to this workgroup's RB output rows (32-bit offsets; samples past the valid window, decimated
   // away or in rows past NY get an out-of-range offset instead of a branch)
-  float* orow = a.dst + (((size_t)img * a.NC + c) * a.NY + y0) * a.Xo;
+  float* orow = a.dst + ((map_img(a.im, img) * a.NC + c) * a.NY + y0) * a.Xo;
   const BufRsrc orr = make_rsrc(orow, (unsigned)((size_t)min(RB, a.NY - y0) * a.Xo * 4));
   const bool has0 = ya_row < a.NY, has1 = ya_row + 1 < a.NY;
   // (offsets are sums of small row and column parts; bit 31 marks a store that must not happen)

@@ -1,6 +1,9 @@
-// wgrad1d.hpp -- weight gradient of the 1-D convolution, stride 1.
+// wgrad1d.hpp -- weight gradient of the 1-D convolution.
 //
-//   dW[o][i][k] = sum_b sum_t dY[b][o][t] * Xp[b][i][t + k*d]          (Xp = padded input)
+//   dW[o][i][k] = sum_b sum_t dY[b][o][t] * Xp[b][i][t*s + k*d]        (Xp = padded input, s = stride)
+//
+// (a strided convolution's gradient is read spread over a grid of step s -- sample t sits at position t*s of the
+// tile, zeros between -- so everything below is the stride-1 scheme on that zero-stuffed row of (Lout-1)*s + 1 samples)
 //
 // is a correlation whose lags 0..kd-1 are wanted, summed over the batch and over the whole row.  In the
 // frequency domain the sum commutes with the transform: per overlap-save tile (V samples of dY against
@@ -26,7 +29,8 @@ struct WGradArgs {
   const f2* twB;
   int B, Cin, Cout, G, Cig, Cog;
   int L, pad, pad_mode, Lout;
-  int K, dil, V, ntiles;           // taps of THIS segment, dilation, dY samples per tile, tiles per row
+  int stride, Lext;                // stride of the convolution, extent of the zero-stuffed gradient row (Lout-1)*stride + 1
+  int K, dil, V, ntiles;           // taps of THIS segment, dilation, gradient positions per tile (a multiple of stride), tiles per row
   int Krow, tap0;                  // taps per weight row, first tap of this segment (kernels longer than one
   int pos_shift;                   //   tile's lag window run in segments: x is read tap0*dil samples further in)
   int n_items, items_per_slice;    // (b, tile) items in all / per slice (a multiple of NB)
@@ -124,13 +128,25 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_kernel(const WGradArgs a) {
         const unsigned ro0 = ((unsigned)b * (unsigned)a.Cout + (unsigned)(g * a.Cog + co0)) * (unsigned)a.Lout * 4u;
         const unsigned ro1 = ro0 + (unsigned)a.Lout * 4u;
         const int t0 = tile * a.V;
-        const int limit = min(a.V, a.Lout - t0);        // gradient samples of this tile (zero beyond)
+        const int limit = min(a.V, a.Lext - t0);        // gradient positions of this tile (zero beyond)
+        if (a.stride == 1) {
 #pragma unroll
-        for (int n1 = 0; n1 < P; ++n1) {
-          const int n = G::N2 * n1 + tseq;
-          const bool in = n < limit;
-          v[n1].x = buf_load_f32(yr, (in && has0) ? ro0 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
-          v[n1].y = buf_load_f32(yr, (in && has1) ? ro1 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+          for (int n1 = 0; n1 < P; ++n1) {
+            const int n = G::N2 * n1 + tseq;
+            const bool in = n < limit;
+            v[n1].x = buf_load_f32(yr, (in && has0) ? ro0 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+            v[n1].y = buf_load_f32(yr, (in && has1) ? ro1 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+          }
+        } else {
+          const int q0 = t0 / a.stride;                  // (t0 is a multiple of the stride)
+#pragma unroll
+          for (int n1 = 0; n1 < P; ++n1) {
+            const int n = G::N2 * n1 + tseq;
+            const int nq = n / a.stride;
+            const bool in = n < limit && nq * a.stride == n;
+            v[n1].x = buf_load_f32(yr, (in && has0) ? ro0 + (unsigned)(q0 + nq) * 4u : 0xFFFFFFFFu, 0);
+            v[n1].y = buf_load_f32(yr, (in && has1) ? ro1 + (unsigned)(q0 + nq) * 4u : 0xFFFFFFFFu, 0);
+          }
         }
       }
       // ---------------------------------------------- forward FFT (wave-local)
@@ -333,13 +349,15 @@ __global__ __launch_bounds__(NT, 2) void wgrad1d_diag_kernel(const WGradArgs a) 
         const unsigned ro0 = ((unsigned)b * (unsigned)a.Cout + (unsigned)c0) * (unsigned)a.Lout * 4u;
         const unsigned ro1 = ro0 + (unsigned)a.Lout * 4u;
         const int t0 = tile * a.V;
-        const int limit = min(a.V, a.Lout - t0);
+        const int limit = min(a.V, a.Lext - t0);
+        const int q0 = t0 / a.stride;
 #pragma unroll
         for (int n1 = 0; n1 < P; ++n1) {
           const int n = G::N2 * n1 + tseq;
-          const bool in = n < limit;
-          v[n1].x = buf_load_f32(yr, in ? ro0 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
-          v[n1].y = buf_load_f32(yr, in ? ro1 + (unsigned)(t0 + n) * 4u : 0xFFFFFFFFu, 0);
+          const int nq = a.stride == 1 ? n : n / a.stride;
+          const bool in = n < limit && nq * a.stride == n;
+          v[n1].x = buf_load_f32(yr, in ? ro0 + (unsigned)(q0 + nq) * 4u : 0xFFFFFFFFu, 0);
+          v[n1].y = buf_load_f32(yr, in ? ro1 + (unsigned)(q0 + nq) * 4u : 0xFFFFFFFFu, 0);
         }
       }
       passA_fft_twiddle_store_lds<G, -1>(v, zseq, tseq, twl);

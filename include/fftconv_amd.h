@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define FC_ABI_VERSION 5
+#define FC_ABI_VERSION 6
 
 enum fc_status {
   FC_OK = 0,
@@ -132,6 +132,19 @@ int fc_wgrad1d(const fc_desc* desc, const float* x, const float* dy, float* part
 int fc_wgrad1d_db_supported(const fc_desc* desc);
 int fc_wgrad1d_db(const fc_desc* desc, const float* x, const float* dy, float* partial, float* db_partial,
                   long long slice_stride, int slices, void* hip_stream);
+
+/* Weight gradient of a 2-D / 3-D convolution (ABI 6; row N1: the reference's dW comes out of autograd through its
+ * rfftn / einsum / irfftn graph, tests/test_functional.py:62-117 pin it for ndim 1-3, stride 1-2, groups 1-3):
+ *   dW[(g,o)][i][k] = sum_b sum_t dY[b][(g,o)][t] * Xpad[b][(g,i)][t*stride + k*dilation]
+ * is the convolution of x with batch and channels exchanged against dY (stride and dilation exchanged too), of which
+ * the first kernel[i] lags per axis are kept.  fc_wgrad_nd_plan_create takes the descriptor OF THE CONVOLUTION and
+ * returns the plan of that gradient (destroy with fc_plan_destroy; fc_kernel_spectrum_bytes / fc_workspace_bytes size the
+ * two scratch buffers).  fc_wgrad_nd transforms dY (B, Cout, *Lout), runs x (B, Cin, *S) against it and writes
+ * dw (Cout, Cin/groups, *k) completely -- both tensors are read and dW is written in these layouts, no transposed
+ * copies, no partial results.  Asynchronous on hip_stream; allocates nothing. */
+int fc_wgrad_nd_plan_create(const fc_desc* conv_desc, fc_plan** out_plan);
+int fc_wgrad_nd(const fc_plan* plan, const float* x, const float* dy, float* dw, void* spectrum, void* workspace,
+                void* hip_stream);
 
 /* Profiling variant of fc_forward (not part of the drop-in surface; the plan stays immutable):
  * `stamps` is a device buffer of 16 * fc_debug_grid(plan) uint64 in which lane 0 of the waves of the

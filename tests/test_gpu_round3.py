@@ -254,3 +254,88 @@ def test_float64_module_trains_through_the_fft_path():
     wr, br = layer.weight.detach().cpu().requires_grad_(), layer.bias.detach().cpu().requires_grad_()
     F.conv1d(xr, wr, br, padding=32).square().sum().backward()
     assert _rel(x.grad, xr.grad) < 1e-10 and _rel(layer.weight.grad, wr.grad) < 1e-10 and _rel(layer.bias.grad, br.grad) < 1e-10
+
+
+# ----------------------------------------------------------------------------- native weight gradients beyond 1-D / stride 1
+def _torch_dw(x, gy, wshape, stride, padding, dilation, groups, mode, want_db=False):
+    """dW (and db) of the reference convolution by torch's autograd in float64 on the CPU."""
+    n = x.ndim - 2
+    xr = x.detach().double().cpu()
+    wr = torch.zeros(wshape, dtype=torch.float64, requires_grad=True)
+    br = torch.zeros(wshape[0], dtype=torch.float64, requires_grad=True)
+    flat = [q for p in reversed(padding) for q in (p, p)]
+    xp = F.pad(xr, flat, mode=mode) if mode != "constant" else F.pad(xr, flat)
+    conv = (F.conv1d, F.conv2d, F.conv3d)[n - 1]
+    conv(xp, wr, br, stride=stride, dilation=dilation, groups=groups).backward(gy.detach().double().cpu())
+    return (wr.grad, br.grad) if want_db else wr.grad
+
+
+WGRAD_ND_CASES = [
+    # B, Cin, Cout, groups, size, k, stride, padding, dilation, mode
+    (4, 8, 8, 1, (96, 100), (15, 15), (1, 1), (0, 0), (1, 1), "constant"),
+    (3, 6, 9, 3, (41, 37), (3, 5), (2, 1), (1, 2), (1, 1), "constant"),           # groups, stride, ragged channels
+    (2, 4, 4, 1, (50, 64), (4, 3), (3, 2), (2, 2), (2, 3), "reflect"),            # stride with unreached tail samples, dilation
+    (12, 3, 5, 1, (33, 40), (5, 5), (1, 2), (2, 0), (1, 2), "circular"),          # batch > 8: the contraction runs in chunks
+    (2, 2, 3, 1, (20, 24, 28), (3, 2, 4), (1, 1, 1), (1, 0, 1), (1, 1, 1), "constant"),
+    (3, 4, 6, 2, (17, 30, 21), (2, 3, 3), (2, 1, 2), (0, 1, 1), (1, 2, 1), "replicate"),
+    (2, 8, 8, 1, (40, 40, 40), (5, 5, 5), (1, 1, 1), (0, 0, 0), (1, 1, 1), "constant"),   # a shape the forward runs plane-major
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_ND_CASES, ids=[f"{len(c[4])}d-k{'x'.join(map(str, c[5]))}-s{'x'.join(map(str, c[6]))}-{c[9]}" for c in WGRAD_ND_CASES])
+def test_wgrad_nd_runs_in_the_library_and_matches_torch(case):
+    """2-D / 3-D dW through fc_wgrad_nd (the tensors as they lie: no transposed copies, no crop) against torch's autograd in
+    float64, and against the round-2 route (forward plans fed by torch transposes) it replaces."""
+    from fft_conv_pytorch_amd import autograd as A
+    b, cin, cout, g, size, k, stride, padding, dilation, mode = case
+    torch.manual_seed(sum(size) + sum(k))
+    x = torch.randn(b, cin, *size, device=DEV)
+    lout = tuple((s + 2 * p - d * (kk - 1) - 1) // st + 1 for s, p, d, kk, st in zip(size, padding, dilation, k, stride))
+    gy = torch.randn(b, cout, *lout, device=DEV)
+    wshape = (cout, cin // g) + tuple(k)
+    got = A._grad_weight_nd_native(x, gy, wshape, stride, padding, dilation, g, mode)
+    assert got is not None and tuple(got.shape) == wshape
+    want = _torch_dw(x, gy, wshape, stride, padding, dilation, g, mode)
+    assert _rel(got, want) < REL_TOL
+    old = A._grad_weight_plans(x, gy, wshape, stride, padding, dilation, g, mode)
+    assert _rel(got, old) < REL_TOL
+    # the operands were read in place: still intact
+    torch.manual_seed(sum(size) + sum(k))
+    assert torch.equal(x, torch.randn(b, cin, *size, device=DEV))
+
+
+def test_wgrad_nd_is_what_the_module_backward_calls(monkeypatch):
+    """FFTConv2d.backward takes dW from fc_wgrad_nd: the torch-transpose route is not entered."""
+    from fft_conv_pytorch_amd import FFTConv2d, autograd as A
+
+    def boom(*a, **k):
+        raise AssertionError("N-d dW went through the forward-plan route")
+    monkeypatch.setattr(A, "_grad_weight_plans", boom)
+    torch.manual_seed(3)
+    layer = FFTConv2d(4, 6, (5, 3), stride=(2, 1), padding=(1, 2), groups=2).to(DEV)
+    x = torch.randn(3, 4, 30, 44, device=DEV, requires_grad=True)
+    y = layer(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    want_w, want_b = _torch_dw(x, gy, tuple(layer.weight.shape), (2, 1), (1, 2), (1, 1), 2, "constant", want_db=True)
+    assert _rel(layer.weight.grad, want_w) < REL_TOL
+    assert _rel(layer.bias.grad, want_b) < REL_TOL
+
+
+@pytest.mark.parametrize("stride,dil,mode,pad", [(2, 1, "constant", 3), (3, 2, "reflect", 5), (5, 1, "circular", 4), (2, 3, "replicate", 2)])
+def test_strided_1d_weight_gradient_runs_in_fc_wgrad1d(stride, dil, mode, pad):
+    """fc_wgrad1d covers strided convolutions (round 3: the gradient row is read spread over the stride's grid); dW and the
+    folded db against torch's autograd in float64 -- long rows (several tiles and slices), tails the stride never reaches."""
+    from fft_conv_pytorch_amd import autograd as A, _native
+    for cin, cout, g, L, k in ((8, 8, 1, 20001, 65), (6, 9, 3, 7003, 17), (4, 4, 1, 5000, 700)):
+        torch.manual_seed(L + k + stride)
+        x = torch.randn(3, cin, L, device=DEV)
+        lout = (L + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        gy = torch.randn(3, cout, lout, device=DEV)
+        desc = _native.conv_desc(1, 3, cin, cout, g, (L,), (k,), (stride,), (pad,), (dil,), _native.PAD_MODES[mode])
+        assert _native.wgrad1d_slices(desc) > 0
+        got = A._grad_weight_native(x, gy, (cout, cin // g, k), (stride,), (pad,), (dil,), g, mode, want_db=True)
+        assert got is not None
+        want_w, want_b = _torch_dw(x, gy, (cout, cin // g, k), (stride,), (pad,), (dil,), g, mode, want_db=True)
+        assert _rel(got[0], want_w) < REL_TOL, (cin, L, k)
+        assert got[1] is not None and _rel(got[1], want_b) < REL_TOL

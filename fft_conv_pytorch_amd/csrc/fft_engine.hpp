@@ -209,6 +209,30 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 using BufRsrc = __amdgpu_buffer_rsrc_t;
 // build from wave-uniform values only (kernel arguments / blockIdx arithmetic)
+// Division of a workgroup index by a launch constant.  A 32-bit integer division costs ~15 VALU instructions per
+// wave (v_rcp_iflag sequence) even though operand and result are uniform; with the multiplier prepared on the host
+// (Granlund-Montgomery: m = floor(2^(31+l) / d) + 1, l = ceil(log2 d), exact for n < 2^31) it is two scalar multiplies
+// and a shift, and the unit maps of the pass kernels (3-7 divisions each) leave the vector pipeline entirely.
+struct FastDiv {
+  unsigned m, sh, d;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.m = (unsigned)(((1ull << (31 + l)) / d) + 1ull);
+  f.sh = 31 + l;
+  f.d = d;
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return (unsigned)(((unsigned long long)n * f.m) >> f.sh); }
+// n -> (n / d, n % d):  q returned, n replaced by the remainder's complement use:  r = n - q*d
+__device__ __forceinline__ unsigned fdivmod(unsigned n, const FastDiv& f, unsigned* q) {
+  *q = fdiv(n, f);
+  return n - *q * f.d;
+}
+
 __device__ __forceinline__ BufRsrc make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }

@@ -140,6 +140,7 @@ struct RowsR2CArgs {
   int nxt, Vx;           // overlap-save tiles along x (rows longer than the largest FFT): tile xt holds the padded
                          // positions [xt*Vx, xt*Vx + T); dst has nxt*Fx bin columns per plane (1, - for one tile)
   ImgMap im;             // where image `img` of this pass sits in src (identity unless a weight-gradient plan)
+  FastDiv d_nyb, d_nxt, d_nc;   // unit map of the launch (filled by the dispatcher)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -153,12 +154,11 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
-  const int nyb = (a.NY + RB - 1) / RB;
-  int id = blockIdx.x;
-  const int yb = id % nyb; id /= nyb;
-  const int xt = id % a.nxt; id /= a.nxt;
-  const int c = id % a.NC;
-  const int img = id / a.NC;
+  unsigned q;
+  const int yb = (int)fdivmod(blockIdx.x, a.d_nyb, &q);
+  const int xt = (int)fdivmod(q, a.d_nxt, &q);
+  const int c = (int)fdivmod(q, a.d_nc, &q);
+  const int img = (int)q;
   const int y0 = yb * RB;
   const int x0 = xt * a.Vx;              // padded position of this tile's first sample
 
@@ -280,6 +280,7 @@ struct C2CArgs {
   // inverse mode: valid samples and decimation; noff = position of this launch's sample 0 on the axis (overlap-save
   // tiles along the middle axis run one launch per tile)
   int NV, stride, noff;
+  FastDiv d_nbb, d_nc;   // unit map of the launch (filled by the dispatcher)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -292,11 +293,10 @@ __global__ __launch_bounds__(NT) void c2c_fwd_kernel(const C2CArgs a) {
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
-  const int nbb = (a.NB + NSEQ - 1) / NSEQ;
-  int id = blockIdx.x;
-  const int bb = id % nbb; id /= nbb;
-  const int c = id % a.NC;
-  const int img = id / a.NC;
+  unsigned q;
+  const int bb = (int)fdivmod(blockIdx.x, a.d_nbb, &q);
+  const int c = (int)fdivmod(q, a.d_nc, &q);
+  const int img = (int)q;
   const int bn0 = bb * NSEQ;
   const bool act = bn0 + sq < a.NB;
 
@@ -358,11 +358,10 @@ __global__ __launch_bounds__(NT) void c2c_inv_kernel(const C2CArgs a) {
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
-  const int nbb = (a.NB + NSEQ - 1) / NSEQ;
-  int id = blockIdx.x;
-  const int bb = id % nbb; id /= nbb;
-  const int c = id % a.NC;
-  const int img = id / a.NC;
+  unsigned q;
+  const int bb = (int)fdivmod(blockIdx.x, a.d_nbb, &q);
+  const int c = (int)fdivmod(q, a.d_nc, &q);
+  const int img = (int)q;
   const int bn0 = bb * NSEQ;
   const bool act = bn0 + sq < a.NB;
   f2 wtw[P];
@@ -421,6 +420,7 @@ struct RowsC2RArgs {
   int NV, stride, Xo;    // valid stride-1 samples along x, decimation, output row length
   int nxt, Vx;           // x tiles (see RowsR2CArgs): tile xt yields the stride-1 samples [xt*Vx, xt*Vx + Vx)
   ImgMap im;             // where image `img` of this pass goes in dst (identity unless a weight-gradient plan)
+  FastDiv d_nyb, d_nxt, d_nc;   // unit map of the launch (filled by the dispatcher)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -434,12 +434,11 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
   const BufRsrc twA = make_rsrc(a.twA, (unsigned)(P * G::N2 * 8));
   const BufRsrc twB = make_rsrc(a.twB, (unsigned)(S * P * 8));
   const int tid = threadIdx.x, sq = tid / G::TS, tseq = tid % G::TS;
-  const int nyb = (a.NY + RB - 1) / RB;
-  int id = blockIdx.x;
-  const int yb = id % nyb; id /= nyb;
-  const int xt = id % a.nxt; id /= a.nxt;
-  const int c = id % a.NC;
-  const int img = id / a.NC;
+  unsigned q;
+  const int yb = (int)fdivmod(blockIdx.x, a.d_nyb, &q);
+  const int xt = (int)fdivmod(q, a.d_nxt, &q);
+  const int c = (int)fdivmod(q, a.d_nc, &q);
+  const int img = (int)q;
   const int y0 = yb * RB;
   const int x0 = xt * a.Vx;                    // first stride-1 sample of this tile
   const int xlim = min(a.Vx, a.NV - x0);       // valid samples the tile contributes
@@ -560,6 +559,7 @@ struct FusedCArgs {
   int Kd, V, ntiles, Lfull, NVo, stride;
   int accumulate;
   unsigned long long* stamps;   // profiling hook: 8 timestamps per workgroup, else null
+  FastDiv d_nbb, d_ncb, d_g, d_noc;   // unit map of the launch (filled by the dispatcher)
 };
 
 // NB batch items of one (column, tile, group, out-chunk) share a workgroup and with it every
@@ -587,15 +587,13 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
   // all workgroups of a column hit the same L2 back to back and the spectrum leaves the
   // Infinity Cache once per XCD instead of once per workgroup.
   //   id = ((((tile*n_ochunks + oc)*G + g)*ncb + colblk)*nbb + bb)*8 + xcd ,  col = colblk*8 + xcd
-  int id = blockIdx.x;
-  const int xcd = id & 7; id >>= 3;
-  const int nbb = (a.B + NB - 1) / NB;
-  const int b0 = (id % nbb) * NB; id /= nbb;
-  const int ncb = (a.ncol + 7) >> 3;
-  const int col = (id % ncb) * 8 + xcd; id /= ncb;
-  const int g = id % a.G; id /= a.G;
-  const int oc = id % a.n_ochunks;
-  const int tile = id / a.n_ochunks;
+  const int xcd = blockIdx.x & 7;
+  unsigned q;
+  const int b0 = (int)fdivmod(blockIdx.x >> 3, a.d_nbb, &q) * NB;
+  const int col = (int)fdivmod(q, a.d_ncb, &q) * 8 + xcd;
+  const int g = (int)fdivmod(q, a.d_g, &q);
+  const int oc = (int)fdivmod(q, a.d_noc, &q);
+  const int tile = (int)q;
   if (col >= a.ncol) return;                 // padding of the last column block (uniform per workgroup)
   const int nbc = min(NB, a.B - b0);         // batch items of this workgroup
   auto stampc = [&](int slot) {
@@ -615,12 +613,31 @@ __global__ __launch_bounds__(NT) void fusedc_kernel(const FusedCArgs a) {
     {
       const int ci = ic * CIB + ch;
       const bool has = ci < a.Cig && nbi < nbc;
-      const f2* s = a.src + (((size_t)(b0 + (has ? nbi : 0)) * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
       f2 v[P];
+      // rows of this workgroup: batch items b0 .. b0+nbc-1, the CIB channels of this chunk, this column -- buffer loads
+      // relative to the first of them (32-bit offsets; idle sequences and samples past NLEN get an offset outside the
+      // resource and read as zero: no branch and no 64-bit address per load)
+      const long long rowlen = (long long)a.ncol * a.NLEN;
+      const long long ispan = ((long long)(nbc - 1) * a.Cin + CIB - 1) * rowlen + a.NLEN;
+      if (ispan * 8 < 0x7fffffffLL) {
+        const f2* s0 = a.src + (((size_t)b0 * a.Cin + (size_t)g * a.Cig + (size_t)ic * CIB) * a.ncol + col) * a.NLEN;
+        const BufRsrc sr = make_rsrc(s0, (unsigned)(ispan * 8));
+        const unsigned ro = has ? (unsigned)((((long long)nbi * a.Cin + ch) * rowlen + t0) * 8) + (unsigned)tseq * 8u : 0x80000000u;
+        if (t0 + T <= a.NLEN) {
 #pragma unroll
-      for (int n1 = 0; n1 < P; ++n1) {
-        const int n = G::N2 * n1 + tseq;
-        v[n1] = (has && t0 + n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
+          for (int n1 = 0; n1 < P; ++n1) v[n1] = buf_load_f32x2(sr, ro, G::N2 * n1 * 8);
+        } else {
+          const int lim = a.NLEN - t0 - tseq;        // sample n1 exists iff N2*n1 < lim
+#pragma unroll
+          for (int n1 = 0; n1 < P; ++n1) v[n1] = buf_load_f32x2(sr, G::N2 * n1 < lim ? ro : 0x80000000u, G::N2 * n1 * 8);
+        }
+      } else {
+        const f2* s = a.src + (((size_t)(b0 + (has ? nbi : 0)) * a.Cin + (size_t)g * a.Cig + (has ? ci : 0)) * a.ncol + col) * a.NLEN + t0;
+#pragma unroll
+        for (int n1 = 0; n1 < P; ++n1) {
+          const int n = G::N2 * n1 + tseq;
+          v[n1] = (has && t0 + n < a.NLEN) ? s[n] : mk2(0.f, 0.f);
+        }
       }
       if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stampc(1); }
       fwd_from_regs<G>(v, zin + sq * LSEQP, tseq, true, twA, twB);

@@ -83,7 +83,9 @@ hipError_t rows_r2c_dispatch(const RowsR2CArgs& a, hipStream_t st) {
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
   const long long grid = (long long)a.NA * a.NC * a.nxt * nyb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  auto b = a;
+  b.d_nyb = make_fastdiv((unsigned)nyb); b.d_nxt = make_fastdiv((unsigned)a.nxt); b.d_nc = make_fastdiv((unsigned)a.NC);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, b);
   return hipGetLastError();
 }
 
@@ -95,16 +97,18 @@ hipError_t c2c_dispatch(const C2CArgs& a, hipStream_t st) {
   const long long grid = (long long)a.NA * a.NC * nbb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
   static LdsOptIn done;
+  C2CArgs b = a;
+  b.d_nbb = make_fastdiv((unsigned)nbb); b.d_nc = make_fastdiv((unsigned)a.NC);
   if (INV) {
     auto k = c2c_inv_kernel<FC_P, FC_S, kNSEQ_C, NT>;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, b);
   } else {
     auto k = c2c_fwd_kernel<FC_P, FC_S, kNSEQ_C, NT>;
     hipError_t e = ensure_lds(k, lds, &done);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, b);
   }
   return hipGetLastError();
 }
@@ -119,7 +123,9 @@ hipError_t rows_c2r_dispatch(const RowsC2RArgs& a, hipStream_t st) {
   const long long nyb = (a.NY + 2 * kNSEQ_R - 1) / (2 * kNSEQ_R);
   const long long grid = (long long)a.NA * a.NC * a.nxt * nyb;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+  auto b = a;
+  b.d_nyb = make_fastdiv((unsigned)nyb); b.d_nxt = make_fastdiv((unsigned)a.nxt); b.d_nc = make_fastdiv((unsigned)a.NC);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, b);
   return hipGetLastError();
 }
 
@@ -145,7 +151,10 @@ hipError_t launch_fusedc_nb(const FusedCArgs& a, hipStream_t st) {
     const long long nbb = (a.B + NB - 1) / NB;
     const long long grid = nbb * a.ntiles * a.n_ochunks * a.G * ((a.ncol + 7) / 8) * 8;
     if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, a);
+    FusedCArgs b = a;
+    b.d_nbb = make_fastdiv((unsigned)nbb); b.d_ncb = make_fastdiv((unsigned)((a.ncol + 7) / 8));
+    b.d_g = make_fastdiv((unsigned)a.G); b.d_noc = make_fastdiv((unsigned)a.n_ochunks);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NT), lds, st, b);
     return hipGetLastError();
   }
 }

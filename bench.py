@@ -88,9 +88,8 @@ def pmc_traffic(config_name, kernel_name):
 def dominant_kernel_name(plan):
     """Name prefix of the kernel that dominates this plan's forward (as rocprofv3 prints it)."""
     tile, ph, nseg, seg_taps, diag, bd_gs, wide, pers_nb = plan.layout
-    if plan.key[0] == 3 and tile == 64 and os.environ.get("FFTCONV_PLANES", "1") != "0" and all(
-            s + 2 * p <= 64 for s, p in zip(plan.key[5][1:], plan.key[8][1:])):
-        return "colz_kernel<"                # plane-major 3-D pipeline: the z pass + channel mix is its longest launch
+    if plan.key[0] != 1 and pers_nb:         # (N-d plans report their pipeline in this word: 1 = 3-D plane-major, 2 = 2-D rows as they are)
+        return "colz_kernel<"                # the thread-per-sequence column pass + channel mix is the longest launch of both
     if plan.key[0] != 1:
         return "fusedc_kernel"
     geo = {64: (8, 1), 128: (8, 2), 256: (16, 1), 512: (16, 2), 1024: (32, 1), 2048: (32, 2), 4096: (32, 4)}.get(tile)

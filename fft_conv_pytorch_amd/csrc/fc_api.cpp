@@ -170,7 +170,8 @@ struct fc_plan {
   int nyt, Vy;                // the same for the middle axis of a 3-D problem (one c2c launch per tile)
   int nd_cob, nd_Cog_pad;
   int f64_T, f64_V, f64_ntiles, f64_cob;   // float64 1-D FFT path (fft_f64.hip): tile, valid samples, tiles per row, out-chunk; 0 = direct kernel
-  int planes;                 // 3-D: plane-major three-launch pipeline (planes3d.hpp) instead of the five separable passes
+  int planes;                 // 1: 3-D plane-major three-launch pipeline (planes3d.hpp) instead of the five separable passes;
+                              // 2: 2-D with the same thread-per-sequence column pass between row passes that keep the rows as they are
   size_t ws_a, ws_b;          // fc::f2 counts of the two workspace regions
   // ---- persistent fused 1-D kernel (fast path)
   int pers_nb;                // batch items per workgroup (0 = fast path not used)
@@ -695,6 +696,19 @@ static int plan_nd(fc_plan* p) {
     planes_ok = (!env || atoi(env) != 0) && !p->swap && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 && p->nxt == 1 &&
                 p->nyt == 1 && p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) &&
                 (int64_t)2 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) < 65536;   // (32-bit offsets below 2 GiB per workgroup)
+    // 2-D: the same column pass (one thread per 64-point sequence along y, lanes over neighbouring bin columns) between
+    // row passes that keep the rows as they are -- taken under the same conditions on the y kernel and the channel blocks
+    // Measured (scripts/experiments/time_rows2d.py, profiles/r03_experiments.md block 10): 5-13 % faster than the LDS column
+    // pass on large images with y kernels up to ~25 taps (B16 512^2 k3..k23, B2 1024^2 k7), level at k31 (a 64-point tile then
+    // keeps 34 samples), 8-10 % slower on small problems (B4 256^2) -- taken from 2^20 intermediate samples per channel and
+    // 25 dilated taps down; FFTCONV_PLANES=2 takes it wherever it is possible (tests), 0 never.
+    if (nd == 2) {
+      const int knob = env ? atoi(env) : 1;
+      const bool big = (int64_t)d.batch * p->Sp[0] * p->Fx >= ((int64_t)1 << 20) && p->kd[0] <= 25;
+      planes_ok = knob != 0 && (big || knob == 2) && !p->swap && t64 && t64->colz && p->nxt == 1 && p->CB == 8 && !p->accumulate &&
+                  p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) && p->Fx % 16 == 0 &&
+                  (int64_t)4 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) * p->Fx * 8 < ((int64_t)1 << 31);
+    }
   }
   // overlap-save tiles along the outermost axis
   const int64_t Kd = p->kd[0], Lfull = p->Lf[0];
@@ -747,8 +761,8 @@ static int plan_nd(fc_plan* p) {
     a_w = Co * p->Cig * (size_t)p->kd[0] * Fx * (size_t)p->kd[1];
     b_w = Co * p->Cig * Fx * Ty * (size_t)p->kd[0];
   }
-  p->planes = planes_ok && best->T == 64;
-  if (p->planes) {
+  p->planes = (planes_ok && best->T == 64) ? (nd == 3 ? 1 : 2) : 0;
+  if (p->planes == 1) {
     a_sig = B * Ci * (size_t)p->Sp[0] * fc::kPlCols;              // S[(b,ci)][zp][col]
     b_sig = B * Co * (size_t)p->out_sp[0] * fc::kPlCols;          // O[(b,co)][z_out][col]
   }
@@ -1023,15 +1037,18 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
   layout[4] = p.diag; layout[5] = p.bd_gs; layout[6] = p.dense ? 2 : p.wide; layout[7] = p.pers_nb;
   if (p.nd != 1) {   // N-d: the spectrum is laid out over the row / middle-axis transform lengths too
     layout[1] = p.tx ? p.tx->T : 0; layout[2] = p.tm ? p.tm->T : 0; layout[3] = p.nd_cob;   // (x tiles share one kernel spectrum)
-    layout[4] = layout[5] = layout[6] = layout[7] = 0;
+    layout[4] = layout[5] = layout[6] = 0;
+    layout[7] = p.planes;      // 1 / 2: the thread-per-sequence column pass (3-D plane-major / 2-D); same spectrum bytes either way
   }
   return FC_OK;
 }
 
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->d.dtype != FC_F32) return 0;
-  if (plan->nd == 3 && plan->planes)   // upper bound of colz's grid (one batch item per workgroup)
-    return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * (fc::kPlCols / 16);
+  if (plan->planes) {   // upper bound of colz's grid (one batch item per workgroup)
+    const long long ncol = plan->planes == 1 ? fc::kPlCols : plan->Fx;
+    return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol / 16 + 7) / 8) * 8;
+  }
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
     const long long ncol = plan->nd == 2 ? plan->Fxt : (long long)plan->Fxt * plan->tm->T * plan->nyt;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol + 7) / 8) * 8;
@@ -1274,7 +1291,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
   const int nd = p.nd;
   const int B = (int)p.d.batch, Ci = (int)p.d.in_channels, Co = (int)p.d.out_channels;
   auto amap = [&](int ax) { fc::AxisMap m; m.size = (int)p.d.spatial[ax]; m.pad = p.padl[ax]; m.mode = p.d.padding_mode; m.up = p.up[ax]; return m; };
-  if (p.planes) {
+  if (p.planes == 1) {
     // x (B,Ci,Z,Y,X) -> S[(b,ci)][zp][col] -> O[(b,co)][z_out][col] -> y; col = fx*64 + fy
     fc::PlaneFwdArgs f1{};
     f1.src = x; f1.dst = wsA; f1.twA = p.twx.twA; f1.twB = p.twx.twB;
@@ -1287,6 +1304,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
     cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
     cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
+    cz.ncol = fc::kPlCols;
     cz.stamps = (unsigned long long*)stamps;        // profiling build of the column pass (scripts/phase_profile_nd.py)
     FC_HIP(p.tile->colz(cz, st));
     fc::PlaneInvArgs f3{};
@@ -1312,6 +1330,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     const unsigned long long bytes = 4ull * (unsigned long long)B * Ci * r.SZ * r.SY * r.SX;
     r.src_bytes = bytes < 0xFFFFFFFFull ? (unsigned)bytes : 0u;
   }
+  r.rowmajor = p.planes == 2;
   if (p.swap) {   // signal = x (B, g*Cig, *S) read as (i, (g, b)): image (i*g + gi)*B + b sits at b*(g*Cig) + gi*Cig + i
     r.im.on = 1; r.im.n1 = (int)p.sw_g; r.im.n2 = (int)p.sw_B; r.im.s0 = 1; r.im.s1 = p.sw_Cig; r.im.s2 = p.sw_g * p.sw_Cig;
   }
@@ -1335,7 +1354,20 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     o.im.on = 1; o.im.n1 = 1; o.im.n2 = (int)(p.sw_g * p.sw_Cog); o.im.s0 = 1; o.im.s1 = 0; o.im.s2 = p.sw_Cig;
   }
 
-  if (nd == 2) {
+  if (nd == 2 && p.planes == 2) {
+    // x (B,Ci,Y,X) -> S[(b,ci)][yp][fx] (rows_r2c above, rows as they are) -> O[(b,co)][y_out][fx] -> y
+    fc::ColZArgs cz{};
+    cz.src = wsA; cz.wspec = (const fc::f4*)w_hat; cz.dst = wsB;
+    cz.B = B; cz.Cin = Ci; cz.Cout = Co; cz.G = (int)p.d.groups; cz.Cig = p.Cig; cz.Cog = p.Cog; cz.Cog_pad = p.nd_Cog_pad;
+    cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
+    cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
+    cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
+    cz.ncol = p.Fx;
+    cz.stamps = (unsigned long long*)stamps;
+    FC_HIP(p.tile->colz(cz, st));
+    o.src = wsB; o.NC = 1; o.rowmajor = 1;
+    FC_HIP(p.tx->rows_c2r(o, st));
+  } else if (nd == 2) {
     f.src = wsA; f.dst = wsB; f.ncol = Fs;
     FC_HIP(p.tile->fusedc(p.CB, f, st));
     o.src = wsB; o.NC = 1;

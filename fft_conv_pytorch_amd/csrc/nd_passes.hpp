@@ -141,6 +141,8 @@ struct RowsR2CArgs {
                          // positions [xt*Vx, xt*Vx + T); dst has nxt*Fx bin columns per plane (1, - for one tile)
   ImgMap im;             // where image `img` of this pass sits in src (identity unless a weight-gradient plan)
   FastDiv d_nyb, d_nxt, d_nc;   // unit map of the launch (filled by the dispatcher)
+  int rowmajor;          // dst [(a*NC + c)][NY][nxt*Fx] instead of the transposed [..][Fx][NYa]: the 2-D pipeline whose column
+                         // pass runs one THREAD per sequence with its lanes over neighbouring bin columns (planes3d.hpp colz)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -238,6 +240,33 @@ __global__ __launch_bounds__(NT) void rows_r2c_kernel(const RowsR2CArgs a) {
   // columns -- 32-bit offsets, rows past NY get an out-of-range offset instead of a branch)
   constexpr int FXC = T / 2;                       // == a.Fx
   static_assert(NT % RB == 0 && (FXC * RB) % NT == 0, "whole rounds, fixed row per thread");
+  if (a.rowmajor) {
+    // rows as they are: a wavefront writes 64 neighbouring bins of one row (512 bytes), both rows of a pair from the same
+    // two LDS reads; rows past NY fall outside the resource (it ends with the last row of this block)
+    constexpr int NIT = FXC * NSEQ / NT;
+    static_assert(NIT * NT == FXC * NSEQ, "whole rounds");
+    const unsigned pitch = (unsigned)(a.nxt * a.Fx);
+    f2* out = a.dst + (((size_t)img * a.NC + c) * a.NY + y0) * pitch + (size_t)xt * a.Fx;
+    const BufRsrc orr = make_rsrc(out, (unsigned)(((size_t)(min(RB, a.NY - y0) - 1) * pitch + FXC) * 8));
+    f2 zf[NIT], zg[NIT];
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int idx = u * NT + tid, s = idx / FXC, fx = idx % FXC;
+      const f2* z = lds + s * LSEQP;
+      zf[u] = z[G::nat(fx)];
+      zg[u] = z[G::nat(T - 1 - fx)];
+    }
+#pragma unroll
+    for (int u = 0; u < NIT; ++u) {
+      const int idx = u * NT + tid, s = idx / FXC, fx = idx % FXC;
+      const f2 ev = mk2(0.5f * (zf[u].x + zg[u].x), 0.5f * (zf[u].y - zg[u].y));
+      const f2 ov = mk2(0.5f * (zf[u].y + zg[u].y), 0.5f * (zg[u].x - zf[u].x));
+      const unsigned off = ((unsigned)(2 * s) * pitch + (unsigned)fx) * 8u;
+      buf_store_f32x2(ev, orr, off, 0);
+      buf_store_f32x2(ov, orr, off + pitch * 8u, 0);
+    }
+    return;
+  }
   constexpr int NROUND = FXC * RB / NT, FSTEP = NT / RB;
   f2* out = a.dst + (((size_t)img * a.NC + c) * a.nxt + xt) * a.Fx * a.NYa + y0;
   const BufRsrc orr = make_rsrc(out, (unsigned)(((size_t)(FXC - 1) * a.NYa + min(RB, a.NYa - y0)) * 8));
@@ -421,6 +450,7 @@ struct RowsC2RArgs {
   int nxt, Vx;           // x tiles (see RowsR2CArgs): tile xt yields the stride-1 samples [xt*Vx, xt*Vx + Vx)
   ImgMap im;             // where image `img` of this pass goes in dst (identity unless a weight-gradient plan)
   FastDiv d_nyb, d_nxt, d_nc;   // unit map of the launch (filled by the dispatcher)
+  int rowmajor;          // src [(a*NC + c)][NY][nxt*Fx] (see RowsR2CArgs)
 };
 
 template <int P, int S, int NSEQ, int NT>
@@ -459,8 +489,32 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
     const int rows_here = a.NY - y0;
     const bool pair16 = ((a.NYa | y0) & 1) == 0 && !(rows_here < RB && (rows_here & 1));
     const unsigned plane_bytes = (unsigned)((size_t)(FXC - 1) * a.NYa * 8 + (size_t)min(RB, a.NYa - y0) * 8);
-    const BufRsrc sr = make_rsrc(in, plane_bytes);
     f2 ya[NITER], yb2[NITER];
+    if (a.rowmajor) {
+      // rows as they are: lanes over neighbouring bins of one row; rows past NY fall outside the resource
+      const unsigned pitch = (unsigned)(a.nxt * a.Fx);
+      const f2* inr = a.src + (((size_t)img * a.NC + c) * a.NY + y0) * pitch + (size_t)xt * a.Fx;
+      const BufRsrc srr = make_rsrc(inr, (unsigned)(((size_t)(min(RB, a.NY - y0) - 1) * pitch + FXC) * 8));
+#pragma unroll
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = u * NT + tid;
+        const int s = idx / FXC, fx = idx % FXC;
+        const unsigned off = idx < TOTAL ? ((unsigned)(2 * s) * pitch + (unsigned)fx) * 8u : 0x80000000u;
+        ya[u] = buf_load_f32x2(srr, off, 0);
+        yb2[u] = buf_load_f32x2(srr, off == 0x80000000u ? off : off + pitch * 8u, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NITER; ++u) {
+        const int idx = u * NT + tid;
+        if (idx < TOTAL) {
+          const int s = idx / FXC, fx = idx % FXC;
+          f2* z = lds + s * LSEQP;
+          z[G::nat(fx)] = mk2(ya[u].x - yb2[u].y, ya[u].y + yb2[u].x);
+          z[G::nat(T - 1 - fx)] = mk2(ya[u].x + yb2[u].y, yb2[u].x - ya[u].y);
+        }
+      }
+    } else {
+    const BufRsrc sr = make_rsrc(in, plane_bytes);
     if (pair16) {
 #pragma unroll
       for (int u = 0; u < NITER; ++u) {
@@ -491,6 +545,7 @@ __global__ __launch_bounds__(NT) void rows_c2r_kernel(const RowsC2RArgs a) {
         z[G::nat(fx)] = mk2(ya[u].x - yb2[u].y, ya[u].y + yb2[u].x);
         z[G::nat(T - 1 - fx)] = mk2(ya[u].x + yb2[u].y, yb2[u].x - ya[u].y);
       }
+    }
     }
   }
   __syncthreads();

@@ -286,6 +286,8 @@ struct ColZArgs {
   int NZ, NZo;           // planes per image on the signal / output side
   int V, ntiles, Lfull, stride;     // overlap-save tiles along z (tile t: padded planes [t*V, t*V + 64))
   unsigned long long* stamps;       // profiling build only: 8 timestamps (100 MHz) per workgroup
+  int ncol;                         // bin columns per plane (a multiple of 16): kPlCols in 3-D, Tx/2 in 2-D
+  FastDiv d_nbp, d_ntiles, d_per, d_g;   // unit map of the launch (filled by the dispatcher; d_per.d = column blocks per XCD)
 };
 
 constexpr int colz_fc(int nb) { return nb >= 2 ? 16 : 8; }      // frequencies per exchange chunk
@@ -296,8 +298,11 @@ constexpr size_t colz_lds_bytes(int nb) { return (size_t)2 * nb * 8 * 16 * (colz
 // halves of the workgroup).  RING spectrum sets (one output channel x 8 inputs = 4 float4) travel per thread.
 // DIAG (timestamp builds only, FFTCONV_COLZ_DIAG): 1 = the kernel-spectrum loads are replaced by register constants,
 // 2 = no LDS exchange barriers' partner work (the mix arithmetic is skipped) -- what-bounds-the-mix experiments.
-template <int NB, int RING, bool STAMPS = false, int DIAG = 0>
+// NCOLC: bin columns per plane as a compile-time constant (the 3-D pipeline: kPlCols), 0 = a.ncol (the 2-D pipeline,
+// where the "planes" are the rows of the half-spectrum and the columns its Tx/2 bins).
+template <int NB, int RING, bool STAMPS = false, int DIAG = 0, int NCOLC = kPlCols>
 __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
+  const int ncol = NCOLC > 0 ? NCOLC : a.ncol;
   constexpr int NT = NB * 128;
   constexpr int FC = colz_fc(NB);
   constexpr int R = NT / (16 * FC);         // threads per bin
@@ -319,20 +324,22 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   stampc(0, false);
   // XCD-aware unit map (see fusedc): workgroups that stream one block of the kernel spectrum sit on one XCD (equal
   // blockIdx % 8) and run back to back (the batch block is the fastest index behind it)
-  int id = blockIdx.x;
-  const int xcd = id & 7; id >>= 3;
-  const int nbp = (a.B + NB - 1) / NB;
-  const int b0 = (id % nbp) * NB; id /= nbp;
-  const int colblk = xcd * (kPlCols / 128) + id % (kPlCols / 128); id /= (kPlCols / 128);
-  const int g = id % a.G; id /= a.G;
-  const int oc = id % a.n_ochunks;
-  const int tile = id / a.n_ochunks;
+  //   id = (((((oc*G + g)*per + colblk_local)*ntiles + tile)*nbp + bb)*8 + xcd : the tiles of a column block follow
+  //   each other on one XCD too (they share the spectrum block and the overlap rows of their inputs)
+  const int xcd = blockIdx.x & 7;
+  unsigned q;
+  const int b0 = (int)fdivmod(blockIdx.x >> 3, a.d_nbp, &q) * NB;
+  const int tile = (int)fdivmod(q, a.d_ntiles, &q);
+  const int colblk = xcd * (int)a.d_per.d + (int)fdivmod(q, a.d_per, &q);
+  const int g = (int)fdivmod(q, a.d_g, &q);
+  const int oc = (int)q;
   const int col0 = colblk * 16;
+  if (col0 >= ncol) return;                  // padding of the last XCD's range of column blocks (uniform per workgroup)
   const int nbc = min(NB, a.B - b0);
   const int t0 = tile * a.V;
   // (plane step of the 64 loads / stores as an opaque scalar: as 64 literal offsets hipcc keeps every one of them in
   // its own SGPR across the kernel and spills)
-  unsigned zstep = kPlCols * 8;
+  unsigned zstep = ncol * 8;
   asm volatile("" : "+s"(zstep));
 
   // ---- sequence owner: (batch slot nb, channel ch, column c)
@@ -342,15 +349,15 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   // twiddle constants fill the SGPR file, hipcc assembled it in VECTOR registers and wrapped every store in a
   // readfirstlane loop)
   const int cend = min(a.cob, a.Cog - oc * a.cob);
-  f2* obase = a.dst + ((size_t)b0 * a.Cout + (size_t)g * a.Cog + (size_t)oc * a.cob) * a.NZo * kPlCols;
-  const BufRsrc orr = make_rsrc(obase, (unsigned)((((size_t)(nbc - 1) * a.Cout + cend) * a.NZo) * kPlCols * 8));
+  f2* obase = a.dst + ((size_t)b0 * a.Cout + (size_t)g * a.Cog + (size_t)oc * a.cob) * a.NZo * ncol;
+  const BufRsrc orr = make_rsrc(obase, (unsigned)((((size_t)(nbc - 1) * a.Cout + cend) * a.NZo) * ncol * 8));
   {
-    const f2* sbase = a.src + ((size_t)b0 * a.Cin + (size_t)g * a.Cig) * a.NZ * kPlCols;
-    const BufRsrc sr = make_rsrc(sbase, (unsigned)((((size_t)(nbc - 1) * a.Cin + a.Cig) * a.NZ) * kPlCols * 8));
+    const f2* sbase = a.src + ((size_t)b0 * a.Cin + (size_t)g * a.Cig) * a.NZ * ncol;
+    const BufRsrc sr = make_rsrc(sbase, (unsigned)((((size_t)(nbc - 1) * a.Cin + a.Cig) * a.NZ) * ncol * 8));
     const bool has_in = ch < a.Cig && nb < nbc;
     // (dead loads / stores: bit 31 of the offset -- every resource here is below 2 GiB, fc_api.cpp plan_nd -- which,
     // unlike an all-ones offset, cannot wrap back into range when the instruction's constant offset is added)
-    const unsigned voff = has_in ? (unsigned)((((size_t)nb * a.Cin + ch) * a.NZ + t0) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    const unsigned voff = has_in ? (unsigned)((((size_t)nb * a.Cin + ch) * a.NZ + t0) * ncol + col0 + c) * 8u : 0x80000000u;
     if (t0 + 64 <= a.NZ) {                                  // (the usual case without a select per load)
       static_for<0, 64>([&](auto nc) {
         constexpr int n = decltype(nc)::value;
@@ -366,11 +373,11 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   // ---- bin owner: (share h of the output channels, frequency fzl of the chunk, column cm); its kernel-spectrum
   // stream does not depend on data
   const int h = tid / (16 * FC), fzl = tid % FC, cm = (tid / FC) % 16;
-  const size_t wrow = (size_t)kPlCols * 64;                 // f4 per (o, ip)
+  const size_t wrow = (size_t)ncol * 64;                 // f4 per (o, ip)
   const f4* wbase = a.wspec + ((size_t)g * a.Cog_pad + (size_t)oc * a.cob) * 4 * wrow;
   const BufRsrc wr_ = make_rsrc(wbase, (unsigned)((size_t)a.cob * 4 * wrow * 16));
   // (lane offset: column, frequency and this thread's first output channel h*SPC -- at most 64 MB)
-  const unsigned wvo = (unsigned)((col0 + cm) * 64 + fzl) * 16u + (unsigned)(h * SPC * 4) * (unsigned)(kPlCols * 64 * 16);
+  const unsigned wvo = (unsigned)((col0 + cm) * 64 + fzl) * 16u + (unsigned)(h * SPC * 4) * (unsigned)(ncol * 64 * 16);
   f4 ring[RING][4];
   auto issue = [&](auto stc) {
     constexpr int st = decltype(stc)::value;
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
     }
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip)
-      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (kPlCols * 64 * 16)));
+      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (ncol * 64 * 16)));
   };
   // (the first sets travel during the forward transform, whose temporaries leave room for two of them)
   constexpr int EARLY = RING < 2 ? RING : 2;
@@ -468,11 +475,11 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   {
     const bool live = nb < nbc && ch < a.cob && oc * a.cob + ch < a.Cog;
     const int limit = min(a.V, a.Lfull - t0);
-    const unsigned vo = live ? (unsigned)((((size_t)nb * a.Cout + ch) * a.NZo) * kPlCols + col0 + c) * 8u : 0x80000000u;
+    const unsigned vo = live ? (unsigned)((((size_t)nb * a.Cout + ch) * a.NZo) * ncol + col0 + c) * 8u : 0x80000000u;
     if (a.stride == 1) {
-      unsigned zstep_st = kPlCols * 8;               // (a copy of its own: shared with the loads, the 64 products stay live in SGPRs)
+      unsigned zstep_st = ncol * 8;               // (a copy of its own: shared with the loads, the 64 products stay live in SGPRs)
       asm volatile("" : "+s"(zstep_st));
-      const unsigned vo1 = live ? vo + (unsigned)t0 * (kPlCols * 8) : 0x80000000u;
+      const unsigned vo1 = live ? vo + (unsigned)t0 * (ncol * 8) : 0x80000000u;
       // blocks of 8 planes: a block inside the valid window is straight-line code behind one scalar branch
       static_for<0, 8>([&](auto bc) {
         constexpr int n0 = 8 * decltype(bc)::value;
@@ -493,7 +500,7 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
         constexpr int n = decltype(nc)::value;
         const int t = t0 + n, idx = t / a.stride;
         const bool ok = live && n < limit && idx * a.stride == t;
-        buf_store_f32x2(v[n], orr, ok ? vo + (unsigned)idx * (kPlCols * 8) : 0x80000000u, 0);
+        buf_store_f32x2(v[n], orr, ok ? vo + (unsigned)idx * (ncol * 8) : 0x80000000u, 0);
       });
     }
   }

@@ -360,19 +360,31 @@ hipError_t planes_inv_dispatch(const PlaneInvArgs& a, int n_images, hipStream_t 
   hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
   return hipGetLastError();
 }
-template <int NB, bool STAMPS = false, int DIAG = 0>
-hipError_t launch_colz(const ColZArgs& a, hipStream_t st) {
+template <int NB, bool STAMPS, int DIAG, int NCOLC>
+hipError_t launch_colz_n(const ColZArgs& a, hipStream_t st) {
   constexpr int RING = NB == 4 ? 3 : 2;
-  auto k = colz_kernel<NB, RING, STAMPS, DIAG>;
+  auto k = colz_kernel<NB, RING, STAMPS, DIAG, NCOLC>;
   const size_t lds = colz_lds_bytes(NB);
   static LdsOptIn done;
   hipError_t e = ensure_lds(k, lds, &done);
   if (e != hipSuccess) return e;
+  if (a.ncol < 16 || a.ncol % 16 || (NCOLC > 0 && a.ncol != NCOLC)) return hipErrorInvalidValue;
   const long long nbp = (a.B + NB - 1) / NB;
-  const long long grid = nbp * a.ntiles * a.n_ochunks * a.G * (kPlCols / 16);
+  const long long per = (a.ncol / 16 + 7) / 8;                  // column blocks per XCD
+  const long long grid = nbp * a.ntiles * a.n_ochunks * a.G * per * 8;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB * 128), lds, st, a);
+  ColZArgs b = a;
+  b.d_nbp = make_fastdiv((unsigned)nbp); b.d_ntiles = make_fastdiv((unsigned)a.ntiles);
+  b.d_per = make_fastdiv((unsigned)per); b.d_g = make_fastdiv((unsigned)a.G);
+  hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB * 128), lds, st, b);
   return hipGetLastError();
+}
+// 3-D pipeline: the column count is the compile-time kPlCols; 2-D pipeline (ncol = Tx/2): the run-time build (no stamps / diag)
+template <int NB, bool STAMPS = false, int DIAG = 0>
+hipError_t launch_colz(const ColZArgs& a, hipStream_t st) {
+  if (a.ncol == kPlCols) return launch_colz_n<NB, STAMPS, DIAG, kPlCols>(a, st);
+  if constexpr (DIAG == 0) return launch_colz_n<NB, STAMPS, 0, 0>(a, st);
+  else return hipErrorInvalidValue;
 }
 template <bool STAMPS = false>
 hipError_t launch_colz2(const ColZArgs& a, hipStream_t st) {

@@ -339,3 +339,60 @@ def test_strided_1d_weight_gradient_runs_in_fc_wgrad1d(stride, dil, mode, pad):
         want_w, want_b = _torch_dw(x, gy, (cout, cin // g, k), (stride,), (pad,), (dil,), g, mode, want_db=True)
         assert _rel(got[0], want_w) < REL_TOL, (cin, L, k)
         assert got[1] is not None and _rel(got[1], want_b) < REL_TOL
+
+
+# ----------------------------------------------------------------------------- 2-D: thread-per-sequence column pass between row passes
+ROWS2D_CASES = [
+    # B, Cin, Cout, groups, size, k, stride, padding, dilation, mode
+    (4, 8, 8, 1, (512, 512), (31, 31), 1, 0, 1, "constant"),              # cfgB at batch 4: 15 overlap-save tiles along y
+    (1, 8, 8, 1, (100, 96), (3, 3), 1, 1, 1, "constant"),                 # one batch item (NB = 1 build), 3 x 3
+    (3, 5, 7, 1, (70, 130), (4, 5), 1, (2, 0), 1, "constant"),            # odd batch, ragged channel counts
+    (2, 8, 24, 1, (90, 61), (5, 3), (2, 3), (2, 1), 1, "constant"),       # strides, three output chunks
+    (2, 16, 8, 2, (64, 200), (3, 7), 1, (1, 3), 1, "reflect"),            # groups, index-map padding
+    (2, 8, 8, 1, (131, 75), (9, 5), 1, 4, (4, 2), "circular"),            # dilated y kernel of 33: the longest of the path
+    (5, 16, 8, 2, (33, 40), (2, 3), (1, 2), 1, 1, "replicate"),           # two groups of 8 -> 4 channels
+    (2, 8, 8, 1, (300, 20), (17, 3), (3, 1), 0, 1, "constant"),           # narrow rows (Tx = 32: 16 bin columns), y stride
+]
+
+
+@pytest.mark.parametrize("case", ROWS2D_CASES, ids=[f"{c[4]}k{c[5]}{c[9]}" for c in ROWS2D_CASES])
+def test_rows2d_pipeline_matches_separable_passes_and_torch(case, monkeypatch):
+    """2-D with a y kernel of at most 33 dilated taps: rows_r2c (rows as they are) / colz (one thread per 64-point y
+    sequence, lanes over bin columns) / rows_c2r against the transposing passes with the LDS column pass
+    (FFTCONV_PLANES=0) and torch's direct convolution in float64."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv, _plan_for
+    B, Ci, Co, g, size, k, s, p, d, mode = case
+    gen = torch.Generator().manual_seed(2000 + sum(size) + B)
+    x = torch.randn(B, Ci, *size, generator=gen).to(DEV)
+    w = (torch.randn(Co, Ci // g, *k, generator=gen) / math.sqrt(Ci // g * math.prod(k))).to(DEV)
+    b = torch.randn(Co, generator=gen).to(DEV)
+    outs, kinds = {}, {}
+    for knob in ("2", "0"):                                  # 2: wherever possible (the planner takes it on large problems only)
+        monkeypatch.setenv("FFTCONV_PLANES", knob)          # (read at plan creation)
+        _native.clear_plan_cache()
+        outs[knob] = fft_conv(x, w, b, stride=s, padding=p, dilation=d, groups=g, padding_mode=mode)
+        tup = lambda v: (v, v) if isinstance(v, int) else tuple(v)
+        kinds[knob] = _plan_for(x, w, b, tup(s), tup(p), tup(d), g, mode).layout[7]
+    assert kinds == {"2": 2, "0": 0}                         # the new pipeline really ran (and the knob really turns it off)
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    if mode == "constant":
+        want = F.conv2d(xd, wd, bd, stride=s, padding=p, dilation=d, groups=g)
+    else:
+        pp = (p,) * 2 if isinstance(p, int) else p
+        want = F.conv2d(F.pad(xd, [q for ax in reversed(pp) for q in (ax, ax)], mode=mode), wd, bd, stride=s, dilation=d, groups=g)
+    assert outs["2"].shape == want.shape and outs["2"].is_contiguous()
+    assert _rel(outs["2"], want) < REL_TOL and _rel(outs["0"], want) < REL_TOL
+    assert _rel(outs["2"], outs["0"]) < 5e-6                 # the two pipelines agree to fp32 rounding
+    monkeypatch.delenv("FFTCONV_PLANES", raising=False)
+    _native.clear_plan_cache()
+
+
+def test_rows2d_pipeline_is_the_planners_choice_on_large_images_only():
+    from fft_conv_pytorch_amd.functional import _plan_for
+    from fft_conv_pytorch_amd import _native
+    _native.clear_plan_cache()
+    pick = lambda b, s, k: _plan_for(torch.empty(b, 8, s, s, device=DEV), torch.empty(8, 8, k, k, device=DEV), None, (1, 1), (0, 0),
+                                     (1, 1), 1, "constant").layout[7]
+    assert pick(16, 512, 7) == 2 and pick(2, 1024, 5) == 2            # large: thread-per-sequence column pass
+    assert pick(4, 256, 7) == 0 and pick(16, 512, 31) == 0            # small problem / long y kernel: LDS column pass

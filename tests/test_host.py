@@ -259,3 +259,30 @@ def test_modules_copy_and_pickle_without_their_native_handles():
         # inside a container, as model-averaging utilities copy whole models
         model = torch.nn.Sequential(layer, torch.nn.ReLU())
         assert torch.equal(copy.deepcopy(model)[0].weight, layer.weight)
+
+
+def test_unit_map_division_constants_are_exact():
+    """csrc/fft_engine.hpp make_fastdiv / fdiv: the pass kernels split blockIdx by launch constants with a host-prepared
+    multiply-shift (m = floor(2^(31+l)/d) + 1, l = ceil(log2 d)); the formula restated here must be exact for every
+    dividend below 2^31 -- a wrong quotient would send a workgroup to another image's rows."""
+    import random
+
+    def make(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        m = ((1 << (31 + l)) // d) + 1
+        assert m < (1 << 32)
+        return m, 31 + l
+
+    rng = random.Random(7)
+    divisors = list(range(1, 600)) + [(1 << k) + e for k in range(1, 31) for e in (-1, 0, 1)] + [rng.randrange(1, 1 << 31) for _ in range(3000)]
+    top = (1 << 31) - 1
+    for d in divisors:
+        m, sh = make(d)
+        q = top // d
+        probes = {0, 1, d - 1, d, min(d + 1, top), top, top - 1, q * d, max(q * d - 1, 0)}
+        probes |= {rng.randrange(0, top + 1) for _ in range(8)}
+        probes |= {min(rng.randrange(0, q + 1) * d + e, top) for e in (0, d - 1) for _ in range(4)}
+        for n in probes:
+            assert (n * m) >> sh == n // d, (n, d)

@@ -142,7 +142,7 @@ report("transposed forward + backward, this library", timed(ours_t_step, args.it
 report("transposed forward + backward, torch conv_transpose1d autograd (MIOpen), same GPU",
        timed(torch_t_step, max(3, args.iters // 10)), B * C * L, t_bwd_bytes)
 
-# 2-D forward + backward (weight gradient through forward plans with batch and channels swapped)
+# 2-D forward + backward (weight gradient by fc_wgrad_nd: the batch / channel-swapped convolution run by the library on the tensors as they lie)
 B2, S2, K2 = 4, 256, 15
 conv2 = fca.FFTConv2d(C, C, K2, bias=True).to(dev)
 x2 = [torch.randn(B2, C, S2, S2, device=dev, requires_grad=True) for _ in range(3)]

@@ -163,6 +163,7 @@ struct fc_plan {
   const fc::TileImpl* tm;     // middle axis (3-D), full-length FFT
   Twiddles twx, twm;
   int Sp[3], Lf[3];           // padded extent / stride-1 output extent per axis
+  int need[3];                // shortest cyclic length that yields all Lf outputs exactly (<= Sp: zero padding absorbs the wrap)
   int padl[3], up[3], ostride[3];   // left pad in grid coordinates, source spread step, output decimation
   int Fx;                     // Tx/2
   int nxt, Vx, Fxt;           // overlap-save tiles along the rows axis (nxt = 1: one full-length transform), valid
@@ -637,7 +638,7 @@ static int plan_nd(fc_plan* p) {
   // (the reference has no size limit: functional.py:66-70); middle axis (3-D): full-length transform
   p->nxt = 1;
   p->Vx = p->Lf[nd - 1];
-  p->tx = smallest_tile_at_least(p->Sp[nd - 1]);
+  p->tx = smallest_tile_at_least(p->need[nd - 1]);
   {
     const char* env = getenv("FFTCONV_XTILE");       // testing knob: force x tiles of this length (where the kernel fits)
     const int64_t kdx = p->kd[nd - 1];
@@ -669,7 +670,7 @@ static int plan_nd(fc_plan* p) {
   p->nyt = 1;
   p->Vy = nd == 3 ? p->Lf[1] : 0;
   if (nd == 3) {
-    p->tm = smallest_tile_at_least(p->Sp[1]);
+    p->tm = smallest_tile_at_least(p->need[1]);
     const char* env = getenv("FFTCONV_YTILE");       // testing knob: force middle-axis tiles of this length
     const int64_t kdy = p->kd[1];
     int forced = env ? atoi(env) : 0;
@@ -682,6 +683,7 @@ static int plan_nd(fc_plan* p) {
       p->Vy = (int)(t->T - kdy + 1);
       p->nyt = (int)((p->Lf[1] + p->Vy - 1) / p->Vy);
     }
+    if (p->nyt == 1) p->Sp[1] = std::min(p->Sp[1], p->tm->T);    // (rows past the transform are zero padding: not produced)
   }
   // channel blocking of the fused (complex) pass: one sequence per channel
   p->nd_cob = std::min(p->CB, p->Cog);
@@ -725,7 +727,7 @@ static int plan_nd(fc_plan* p) {
     const size_t lds = (size_t)(p->accumulate ? 2 : 1) * p->CB * t->lseqp * sizeof(fc::f2);
     if (lds > lds_cap) continue;
     const int64_t V = t->T - Kd + 1;
-    const int64_t nt = (Lfull + V - 1) / V;
+    const int64_t nt = t->T >= p->need[0] ? 1 : (Lfull + V - 1) / V;     // (one tile when the zero padding absorbs the wrap)
     double cost = (double)nt * t->T * (2.0 * std::log2((double)t->T) + 4.0 + 2.0 * p->CB);
     if (lds > 80 * 1024) cost *= 1.25;
     if (!best || cost < best_cost) { best = t; best_cost = cost; }
@@ -736,8 +738,15 @@ static int plan_nd(fc_plan* p) {
                 (long long)Kd, p->CB);
   }
   p->tile = best;
-  p->V = (int)(best->T - Kd + 1);
-  p->ntiles = (int)((Lfull + p->V - 1) / p->V);
+  if (best->T >= p->need[0]) {
+    // the whole axis in one cyclic tile: every one of its Lfull outputs is kept, padded positions past the tile are zero
+    p->V = (int)std::max<int64_t>(best->T - Kd + 1, Lfull);
+    p->ntiles = 1;
+    p->Sp[0] = std::min(p->Sp[0], best->T);
+  } else {
+    p->V = (int)(best->T - Kd + 1);
+    p->ntiles = (int)((Lfull + p->V - 1) / p->V);
+  }
   p->Lfull = (int)Lfull;
   p->lds_conv = (size_t)(p->accumulate ? 2 : 1) * p->CB * best->lseqp * sizeof(fc::f2);
 
@@ -803,6 +812,22 @@ static int plan_create_impl(const fc_desc* desc, const WgradSwap* sw, fc_plan** 
     delete p;
     return fail(FC_ERR_INVALID, "a transposed plan supports zero padding only");
   }
+  // A cyclic transform of length T >= Sp holds the whole padded axis.  With ZERO padding a shorter one does: output n reads
+  // the padded positions n .. n+kd-1; those past T wrap to the head of the tile, and the result is unchanged when both the
+  // true sample (position >= T) and the one wrapped in (position - T) are zero -- all data inside the tile (T >= padl + size)
+  // and the wrapped range inside the left padding (T >= size + padr).  The input gradient of an unpadded convolution is the
+  // case that matters: its padded axis is size + 2(kd-1) = out + kd - 1 long, just past the power of two the image has, and
+  // out itself is enough (cfgB dX: 512 instead of 1024-point rows and one 512-point column tile instead of several).
+  const char* zw_env = getenv("FFTCONV_ZEROWRAP");
+  const bool zero_wrap = !zw_env || atoi(zw_env) != 0;
+  auto set_need = [&](int i) {
+    int64_t need = p->Sp[i];
+    const int64_t size_eff = (d.spatial[i] - 1) * p->up[i] + 1;
+    const int64_t padr = p->Sp[i] - p->padl[i] - size_eff;
+    if (zero_wrap && d.padding_mode == FC_PAD_CONSTANT && p->padl[i] >= 0 && padr >= 0)
+      need = std::min<int64_t>(need, std::max<int64_t>(std::max<int64_t>(p->Lf[i], p->kd[i]), std::max<int64_t>(p->padl[i] + size_eff, size_eff + padr)));
+    p->need[i] = (int)need;
+  };
   for (int i = 0; i < d.ndim; ++i) {
     if (d.spatial[i] < 1 || d.kernel[i] < 1 || d.stride[i] < 1 || d.dilation[i] < 1 || d.padding[i] < 0 ||
         (d.transposed && d.output_padding[i] < 0)) {
@@ -823,6 +848,7 @@ static int plan_create_impl(const fc_desc* desc, const WgradSwap* sw, fc_plan** 
       p->ostride[i] = 1;
       p->Sp[i] = (int)(out + p->kd[i] - 1);
       p->Lf[i] = (int)out;
+      set_need(i);
       continue;
     }
     const int64_t span = d.spatial[i] + 2 * d.padding[i] - p->kd[i];
@@ -844,6 +870,7 @@ static int plan_create_impl(const fc_desc* desc, const WgradSwap* sw, fc_plan** 
       p->Lf[i] = (int)((sw->keep[i] - 1) * d.stride[i] + 1);
       p->Sp[i] = (int)(p->Lf[i] + p->kd[i] - 1);
     }
+    set_need(i);
     if (d.padding_mode == FC_PAD_REFLECT && d.padding[i] >= d.spatial[i]) {
       delete p;
       return fail(FC_ERR_INVALID, "axis %d: reflect padding (%lld) must be smaller than the input size (%lld)", i,

@@ -396,3 +396,51 @@ def test_rows2d_pipeline_is_the_planners_choice_on_large_images_only():
                                      (1, 1), 1, "constant").layout[7]
     assert pick(16, 512, 7) == 2 and pick(2, 1024, 5) == 2            # large: thread-per-sequence column pass
     assert pick(4, 256, 7) == 0 and pick(16, 512, 31) == 0            # small problem / long y kernel: LDS column pass
+
+
+# ----------------------------------------------------------------------------- zero padding absorbs the cyclic wrap: shorter transforms
+ZEROWRAP_CASES = [
+    # nd, B, C, size, k, stride, padding, transposed
+    (2, 2, 8, (98, 114), (31, 15), (1, 1), (0, 0), True),        # dX of an unpadded convolution: out = 128 x 128 exactly
+    (3, 2, 8, (56, 56, 56), (9, 9, 9), (1, 1, 1), (0, 0, 0), True),   # cfgC's dX: 64^3, the plane-major pipeline becomes eligible
+    (2, 2, 4, (30, 41), (5, 4), (2, 3), (1, 0), True),           # strides spread the source, padding crops: y 61 of 65
+    (2, 3, 8, (250, 120), (11, 9), (1, 1), (4, 5), False),       # padded forward convolution: size + pad fits where size + 2 pad does not
+    (3, 1, 3, (20, 30, 61), (3, 5, 4), (1, 2, 1), (1, 1, 3), False),
+]
+
+
+@pytest.mark.parametrize("case", ZEROWRAP_CASES, ids=[f"{c[0]}d-{'x'.join(map(str, c[3]))}-k{'x'.join(map(str, c[4]))}-{'T' if c[7] else 'F'}" for c in ZEROWRAP_CASES])
+def test_zero_padding_absorbs_the_wrap_of_a_shorter_transform(case, monkeypatch):
+    """With zero padding a cyclic transform shorter than the padded axis is exact when all data and the wrapped-in range lie
+    inside the tile (fc_api.cpp set_need): same results as with FFTCONV_ZEROWRAP=0 and as torch float64, shorter plans."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv, fft_conv_transpose, _plan_for
+    nd, B, C, size, k, stride, padding, transposed = case
+    gen = torch.Generator().manual_seed(3000 + sum(size))
+    x = torch.randn(B, C, *size, generator=gen).to(DEV)
+    w = (torch.randn(C, C, *k, generator=gen) / math.sqrt(C * math.prod(k))).to(DEV)
+    b = torch.randn(C, generator=gen).to(DEV)
+    outs, tiles = {}, {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("FFTCONV_ZEROWRAP", knob)          # (read at plan creation)
+        _native.clear_plan_cache()
+        if transposed:
+            outs[knob] = fft_conv_transpose(x, w, b, stride=stride, padding=padding)
+            plan = _plan_for(x, w, b, stride, padding, (1,) * nd, 1, "constant", transposed=True, output_padding=(0,) * nd)
+        else:
+            outs[knob] = fft_conv(x, w, b, stride=stride, padding=padding)
+            plan = _plan_for(x, w, b, stride, padding, (1,) * nd, 1, "constant")
+        tiles[knob] = plan.layout[:3]
+    monkeypatch.delenv("FFTCONV_ZEROWRAP", raising=False)
+    _native.clear_plan_cache()
+    xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
+    if transposed:
+        want = (F.conv_transpose2d if nd == 2 else F.conv_transpose3d)(xd, wd, bd, stride=stride, padding=padding)
+    else:
+        want = (F.conv2d if nd == 2 else F.conv3d)(xd, wd, bd, stride=stride, padding=padding)
+    assert outs["1"].shape == want.shape
+    assert _rel(outs["1"], want) < REL_TOL and _rel(outs["0"], want) < REL_TOL
+    assert _rel(outs["1"], outs["0"]) < 5e-6
+    # (outermost tile, row transform, middle transform): the row / middle transforms never grow, and something got shorter
+    # (the outermost axis may trade several short overlap-save tiles for one longer cyclic tile)
+    assert tiles["1"][1] <= tiles["0"][1] and tiles["1"][2] <= tiles["0"][2] and tiles["1"] != tiles["0"], tiles

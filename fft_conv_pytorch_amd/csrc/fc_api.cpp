@@ -651,6 +651,28 @@ static int plan_nd(fc_plan* p) {
       p->tx = t;
       p->Vx = (int)(t->T - kdx + 1);
       p->nxt = (int)((p->Lf[nd - 1] + p->Vx - 1) / p->Vx);
+    } else if (!env && !p->swap) {
+      // A row just past a power of two ('same' padding on a power-of-two image: 518 samples -> a 1024-point transform, and
+      // twice the bin columns for every pass behind it) is cheaper in overlap-save tiles of a quarter of that length: the
+      // points per row decide (measured, scripts/experiments/sweep_same_xtile.py: B16 512^2 k7 'same' 499 us with one
+      // 1024-point transform, 281 us in 128-point tiles, 342 in 256-point ones; B8 1024^2 k5 1,209 / 537).  Taken when it
+      // saves at least 15 % of the points; tiles keep at least half of themselves and are at least 64 long.
+      const int64_t single = p->tx->T;
+      int64_t best_pts = single;
+      const fc::TileImpl* best_t = nullptr;
+      int ntl2;
+      auto tl = all_tiles(&ntl2);
+      for (int i = 0; i < ntl2; ++i) {
+        const fc::TileImpl* t = tl[i];
+        if (t->T < 64 || t->T >= single || t->T < 2 * kdx) continue;
+        const int64_t V = t->T - kdx + 1, n = (p->Lf[nd - 1] + V - 1) / V, pts = n * t->T;
+        if (pts * 100 <= single * 85 && pts < best_pts) { best_pts = pts; best_t = t; }
+      }
+      if (best_t) {
+        p->tx = best_t;
+        p->Vx = (int)(best_t->T - kdx + 1);
+        p->nxt = (int)((p->Lf[nd - 1] + p->Vx - 1) / p->Vx);
+      }
     }
   }
   p->Fx = p->tx->T / 2;        // odd-frequency bins along the rows axis (nd_passes.hpp, rows_r2c)
@@ -682,6 +704,24 @@ static int plan_nd(fc_plan* p) {
       p->tm = t;
       p->Vy = (int)(t->T - kdy + 1);
       p->nyt = (int)((p->Lf[1] + p->Vy - 1) / p->Vy);
+    } else if (!env && !p->swap) {
+      // the same choice as on the rows axis: overlap-save tiles (one c2c launch per tile) where they save >= 15 % of the points
+      const int64_t single = p->tm->T;
+      int64_t best_pts = single;
+      const fc::TileImpl* best_t = nullptr;
+      int ntl2;
+      auto tl = all_tiles(&ntl2);
+      for (int i = 0; i < ntl2; ++i) {
+        const fc::TileImpl* t = tl[i];
+        if (t->T < 64 || t->T >= single || t->T < 2 * kdy) continue;
+        const int64_t V = t->T - kdy + 1, n = (p->Lf[1] + V - 1) / V, pts = n * t->T;
+        if (n <= 8 && pts * 100 <= single * 85 && pts < best_pts) { best_pts = pts; best_t = t; }
+      }
+      if (best_t) {
+        p->tm = best_t;
+        p->Vy = (int)(best_t->T - kdy + 1);
+        p->nyt = (int)((p->Lf[1] + p->Vy - 1) / p->Vy);
+      }
     }
     if (p->nyt == 1) p->Sp[1] = std::min(p->Sp[1], p->tm->T);    // (rows past the transform are zero padding: not produced)
   }

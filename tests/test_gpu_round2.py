@@ -289,15 +289,22 @@ def test_tensor_on_a_non_current_device():
         fft_conv(x, w.to("cuda:0"))
 
 
-def test_nd_block_of_bin_columns_beyond_2_gib_is_refused():
+def test_nd_block_of_bin_columns_beyond_2_gib_is_refused(monkeypatch):
     """The row passes address one block of bin columns per workgroup with 32-bit byte offsets: a second-to-last axis so long
     that Tx/2 bin columns of it span 2 GiB is refused at plan creation (a documented limit) instead of
-    computing with wrapped offsets.  Just below the limit the same shape family still runs."""
+    computing with wrapped offsets.  Just below the limit the same shape family still runs.  (Since round 3 the planner cuts a
+    600-sample row into 64-point tiles -- 32 bin columns, far below the limit -- so the refusal is provoked with the single
+    1024-point transform of round 2, FFTCONV_XTILE=0.)"""
+    from fft_conv_pytorch_amd import _native
     from fft_conv_pytorch_amd.functional import fft_conv
     w = torch.randn(1, 1, 3, 3, device=DEV)
     x = torch.empty(1, 1, 540000, 600, device=DEV)             # padded row 600 -> 1024-point transforms, 512 bin columns
+    monkeypatch.setenv("FFTCONV_XTILE", "0")
+    _native.clear_plan_cache()
     with pytest.raises(NotImplementedError, match="2 GiB"):
         fft_conv(x, w)
+    monkeypatch.delenv("FFTCONV_XTILE")
+    _native.clear_plan_cache()
     del x
     x = torch.randn(1, 1, 300000, 40, device=DEV)              # 64-point transforms: 32 columns x 300000 rows = 77 MB
     y = fft_conv(x, w)

@@ -368,6 +368,7 @@ def test_rows2d_pipeline_matches_separable_passes_and_torch(case, monkeypatch):
     w = (torch.randn(Co, Ci // g, *k, generator=gen) / math.sqrt(Ci // g * math.prod(k))).to(DEV)
     b = torch.randn(Co, generator=gen).to(DEV)
     outs, kinds = {}, {}
+    monkeypatch.setenv("FFTCONV_XTILE", "0")                 # (one row transform: rows cut into x tiles keep the LDS column pass)
     for knob in ("2", "0"):                                  # 2: wherever possible (the planner takes it on large problems only)
         monkeypatch.setenv("FFTCONV_PLANES", knob)          # (read at plan creation)
         _native.clear_plan_cache()
@@ -384,6 +385,7 @@ def test_rows2d_pipeline_matches_separable_passes_and_torch(case, monkeypatch):
     assert outs["2"].shape == want.shape and outs["2"].is_contiguous()
     assert _rel(outs["2"], want) < REL_TOL and _rel(outs["0"], want) < REL_TOL
     assert _rel(outs["2"], outs["0"]) < 5e-6                 # the two pipelines agree to fp32 rounding
+    monkeypatch.delenv("FFTCONV_XTILE", raising=False)
     monkeypatch.delenv("FFTCONV_PLANES", raising=False)
     _native.clear_plan_cache()
 
@@ -421,6 +423,8 @@ def test_zero_padding_absorbs_the_wrap_of_a_shorter_transform(case, monkeypatch)
     w = (torch.randn(C, C, *k, generator=gen) / math.sqrt(C * math.prod(k))).to(DEV)
     b = torch.randn(C, generator=gen).to(DEV)
     outs, tiles = {}, {}
+    monkeypatch.setenv("FFTCONV_XTILE", "0")                  # (single row / middle transforms: the comparison below is about their
+    monkeypatch.setenv("FFTCONV_YTILE", "0")                  #  length, which the planner's overlap-save tiles would hide)
     for knob in ("1", "0"):
         monkeypatch.setenv("FFTCONV_ZEROWRAP", knob)          # (read at plan creation)
         _native.clear_plan_cache()
@@ -431,7 +435,8 @@ def test_zero_padding_absorbs_the_wrap_of_a_shorter_transform(case, monkeypatch)
             outs[knob] = fft_conv(x, w, b, stride=stride, padding=padding)
             plan = _plan_for(x, w, b, stride, padding, (1,) * nd, 1, "constant")
         tiles[knob] = plan.layout[:3]
-    monkeypatch.delenv("FFTCONV_ZEROWRAP", raising=False)
+    for name in ("FFTCONV_ZEROWRAP", "FFTCONV_XTILE", "FFTCONV_YTILE"):
+        monkeypatch.delenv(name, raising=False)
     _native.clear_plan_cache()
     xd, wd, bd = x.double().cpu(), w.double().cpu(), b.double().cpu()
     if transposed:

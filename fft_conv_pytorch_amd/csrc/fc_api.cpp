@@ -746,10 +746,10 @@ static int plan_nd(fc_plan* p) {
     // 25 dilated taps down; FFTCONV_PLANES=2 takes it wherever it is possible (tests), 0 never.
     if (nd == 2) {
       const int knob = env ? atoi(env) : 1;
-      const bool big = (int64_t)d.batch * p->Sp[0] * p->Fx >= ((int64_t)1 << 20) && p->kd[0] <= 25;
-      planes_ok = knob != 0 && (big || knob == 2) && !p->swap && t64 && t64->colz && p->nxt == 1 && p->CB == 8 && !p->accumulate &&
+      const bool big = (int64_t)d.batch * p->Sp[0] * p->Fxt >= ((int64_t)1 << 20) && p->kd[0] <= 25;
+      planes_ok = knob != 0 && (big || knob == 2) && !p->swap && t64 && t64->colz && p->CB == 8 && !p->accumulate &&
                   p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) && p->Fx % 16 == 0 &&
-                  (int64_t)4 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) * p->Fx * 8 < ((int64_t)1 << 31);
+                  (int64_t)4 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) * p->Fxt * 8 < ((int64_t)1 << 31);
     }
   }
   // overlap-save tiles along the outermost axis
@@ -1113,7 +1113,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->d.dtype != FC_F32) return 0;
   if (plan->planes) {   // upper bound of colz's grid (one batch item per workgroup)
-    const long long ncol = plan->planes == 1 ? fc::kPlCols : plan->Fx;
+    const long long ncol = plan->planes == 1 ? fc::kPlCols : plan->Fxt;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol / 16 + 7) / 8) * 8;
   }
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
@@ -1371,7 +1371,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
     cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
     cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
-    cz.ncol = fc::kPlCols;
+    cz.ncol = fc::kPlCols; cz.hcol = fc::kPlCols;
     cz.stamps = (unsigned long long*)stamps;        // profiling build of the column pass (scripts/phase_profile_nd.py)
     FC_HIP(p.tile->colz(cz, st));
     fc::PlaneInvArgs f3{};
@@ -1429,7 +1429,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
     cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
     cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
-    cz.ncol = p.Fx;
+    cz.ncol = Fs; cz.hcol = p.Fx;        // (all x tiles of the signal; they share the Tx/2 spectrum columns)
     cz.stamps = (unsigned long long*)stamps;
     FC_HIP(p.tile->colz(cz, st));
     o.src = wsB; o.NC = 1; o.rowmajor = 1;

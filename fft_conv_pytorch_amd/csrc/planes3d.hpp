@@ -286,8 +286,9 @@ struct ColZArgs {
   int NZ, NZo;           // planes per image on the signal / output side
   int V, ntiles, Lfull, stride;     // overlap-save tiles along z (tile t: padded planes [t*V, t*V + 64))
   unsigned long long* stamps;       // profiling build only: 8 timestamps (100 MHz) per workgroup
-  int ncol;                         // bin columns per plane (a multiple of 16): kPlCols in 3-D, Tx/2 in 2-D
-  FastDiv d_nbp, d_ntiles, d_per, d_g;   // unit map of the launch (filled by the dispatcher; d_per.d = column blocks per XCD)
+  int ncol;                         // bin columns per plane (a multiple of 16): kPlCols in 3-D, nxt * Tx/2 in 2-D
+  int hcol;                         // columns of the kernel spectrum: ncol in 3-D, Tx/2 in 2-D (the x tiles share them)
+  FastDiv d_nbp, d_ntiles, d_per, d_g, d_hcol;   // unit map of the launch (filled by the dispatcher; d_per.d = column blocks per XCD)
 };
 
 constexpr int colz_fc(int nb) { return nb >= 2 ? 16 : 8; }      // frequencies per exchange chunk
@@ -373,11 +374,15 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
   // ---- bin owner: (share h of the output channels, frequency fzl of the chunk, column cm); its kernel-spectrum
   // stream does not depend on data
   const int h = tid / (16 * FC), fzl = tid % FC, cm = (tid / FC) % 16;
-  const size_t wrow = (size_t)ncol * 64;                 // f4 per (o, ip)
+  // (the kernel spectrum has hcol columns: all of them in 3-D; in 2-D the Tx/2 columns of ONE x tile, which the x tiles of
+  // the signal share -- a block of 16 columns lies inside one tile, its spectrum columns start at col0 % hcol)
+  const int hcol = NCOLC > 0 ? NCOLC : a.hcol;
+  const int hc0 = NCOLC > 0 ? col0 : (int)(col0 - (int)fdiv((unsigned)col0, a.d_hcol) * hcol);
+  const size_t wrow = (size_t)hcol * 64;                 // f4 per (o, ip)
   const f4* wbase = a.wspec + ((size_t)g * a.Cog_pad + (size_t)oc * a.cob) * 4 * wrow;
   const BufRsrc wr_ = make_rsrc(wbase, (unsigned)((size_t)a.cob * 4 * wrow * 16));
   // (lane offset: column, frequency and this thread's first output channel h*SPC -- at most 64 MB)
-  const unsigned wvo = (unsigned)((col0 + cm) * 64 + fzl) * 16u + (unsigned)(h * SPC * 4) * (unsigned)(ncol * 64 * 16);
+  const unsigned wvo = (unsigned)((hc0 + cm) * 64 + fzl) * 16u + (unsigned)(h * SPC * 4) * (unsigned)(hcol * 64 * 16);
   f4 ring[RING][4];
   auto issue = [&](auto stc) {
     constexpr int st = decltype(stc)::value;
@@ -396,7 +401,7 @@ __global__ __launch_bounds__(NB * 128, 2) void colz_kernel(const ColZArgs a) {
     }
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip)
-      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (ncol * 64 * 16)));
+      ring[st % RING][ip] = buf_load_f32x4(wr_, vo, (unsigned)((k * 4 + ip) * (hcol * 64 * 16)));
   };
   // (the first sets travel during the forward transform, whose temporaries leave room for two of them)
   constexpr int EARLY = RING < 2 ? RING : 2;

@@ -376,6 +376,9 @@ hipError_t launch_colz_n(const ColZArgs& a, hipStream_t st) {
   ColZArgs b = a;
   b.d_nbp = make_fastdiv((unsigned)nbp); b.d_ntiles = make_fastdiv((unsigned)a.ntiles);
   b.d_per = make_fastdiv((unsigned)per); b.d_g = make_fastdiv((unsigned)a.G);
+  if (b.hcol <= 0) b.hcol = a.ncol;
+  if (b.hcol % 16 || a.ncol % b.hcol) return hipErrorInvalidValue;
+  b.d_hcol = make_fastdiv((unsigned)b.hcol);
   hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(NB * 128), lds, st, b);
   return hipGetLastError();
 }

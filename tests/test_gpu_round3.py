@@ -352,6 +352,8 @@ ROWS2D_CASES = [
     (2, 8, 8, 1, (131, 75), (9, 5), 1, 4, (4, 2), "circular"),            # dilated y kernel of 33: the longest of the path
     (5, 16, 8, 2, (33, 40), (2, 3), (1, 2), 1, 1, "replicate"),           # two groups of 8 -> 4 channels
     (2, 8, 8, 1, (300, 20), (17, 3), (3, 1), 0, 1, "constant"),           # narrow rows (Tx = 32: 16 bin columns), y stride
+    (2, 8, 8, 1, (256, 512), (7, 7), 1, 3, 1, "constant"),                # 'same' padding on a power of two: rows in nine 64-point x tiles
+    (3, 8, 16, 1, (40, 300), (5, 9), (1, 2), (2, 4), 1, "constant"),      # x tiles, two output chunks, x stride
 ]
 
 
@@ -368,7 +370,6 @@ def test_rows2d_pipeline_matches_separable_passes_and_torch(case, monkeypatch):
     w = (torch.randn(Co, Ci // g, *k, generator=gen) / math.sqrt(Ci // g * math.prod(k))).to(DEV)
     b = torch.randn(Co, generator=gen).to(DEV)
     outs, kinds = {}, {}
-    monkeypatch.setenv("FFTCONV_XTILE", "0")                 # (one row transform: rows cut into x tiles keep the LDS column pass)
     for knob in ("2", "0"):                                  # 2: wherever possible (the planner takes it on large problems only)
         monkeypatch.setenv("FFTCONV_PLANES", knob)          # (read at plan creation)
         _native.clear_plan_cache()
@@ -385,7 +386,6 @@ def test_rows2d_pipeline_matches_separable_passes_and_torch(case, monkeypatch):
     assert outs["2"].shape == want.shape and outs["2"].is_contiguous()
     assert _rel(outs["2"], want) < REL_TOL and _rel(outs["0"], want) < REL_TOL
     assert _rel(outs["2"], outs["0"]) < 5e-6                 # the two pipelines agree to fp32 rounding
-    monkeypatch.delenv("FFTCONV_XTILE", raising=False)
     monkeypatch.delenv("FFTCONV_PLANES", raising=False)
     _native.clear_plan_cache()
 

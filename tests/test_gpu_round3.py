@@ -451,3 +451,49 @@ def test_zero_padding_absorbs_the_wrap_of_a_shorter_transform(case, monkeypatch)
     assert tiles["1"][1] <= tiles["0"][1] and tiles["1"][2] <= tiles["0"][2], tiles
     if tuple(size) != (30, 41):          # (there the saving is the tile COUNT of the outermost axis, which the layout words do not show)
         assert tiles["1"] != tiles["0"], tiles
+
+
+AUTOTILE_CASES = [
+    # nd, B, Cin, Cout, groups, size, k, stride, padding, mode
+    (2, 2, 8, 8, 1, (90, 300), (5, 5), (1, 1), (2, 2), "constant"),          # 304 samples -> five 64-point x tiles instead of 512 points
+    (2, 3, 4, 6, 2, (150, 150), (3, 7), (1, 2), (1, 3), "reflect"),          # index-map padding, x stride
+    (3, 1, 4, 4, 1, (20, 150, 170), (3, 3, 5), (1, 1, 1), (1, 1, 2), "constant"),   # 3-D: middle axis AND rows in tiles
+    (3, 2, 8, 8, 1, (30, 140, 40), (2, 9, 3), (1, 2, 1), (0, 4, 1), "circular"),    # middle axis only, stride on it
+]
+
+
+@pytest.mark.parametrize("case", AUTOTILE_CASES, ids=[f"{c[0]}d-{'x'.join(map(str, c[5]))}-{c[9]}" for c in AUTOTILE_CASES])
+def test_rows_just_past_a_power_of_two_run_in_tiles_and_match_torch(case, monkeypatch):
+    """The planner cuts rows / the middle axis into overlap-save tiles where that saves >= 15 % of the points (fc_api.cpp
+    plan_nd): forward, dX, dW and db against torch float64, and the forward against the single-transform plan (knobs = 0)."""
+    from fft_conv_pytorch_amd import _native
+    from fft_conv_pytorch_amd.functional import fft_conv, _plan_for
+    nd, B, Ci, Co, g, size, k, stride, padding, mode = case
+    gen = torch.Generator().manual_seed(4000 + sum(size))
+    x = torch.randn(B, Ci, *size, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(Co, Ci // g, *k, generator=gen) / math.sqrt(Ci // g * math.prod(k))).to(DEV).requires_grad_()
+    b = torch.randn(Co, generator=gen).to(DEV).requires_grad_()
+    _native.clear_plan_cache()
+    y = fft_conv(x, w, b, stride=stride, padding=padding, groups=g, padding_mode=mode)
+    tiled = _plan_for(x, w, b, stride, padding, (1,) * nd, g, mode).layout[:3]
+    gy = torch.randn(y.shape, generator=gen).to(DEV)
+    y.backward(gy)
+    monkeypatch.setenv("FFTCONV_XTILE", "0")
+    monkeypatch.setenv("FFTCONV_YTILE", "0")
+    _native.clear_plan_cache()
+    with torch.no_grad():
+        y_single = fft_conv(x, w, b, stride=stride, padding=padding, groups=g, padding_mode=mode)
+    single = _plan_for(x, w, b, stride, padding, (1,) * nd, g, mode).layout[:3]
+    monkeypatch.delenv("FFTCONV_XTILE")
+    monkeypatch.delenv("FFTCONV_YTILE")
+    _native.clear_plan_cache()
+    assert tiled != single and tiled[1] <= single[1] and tiled[2] <= single[2], (tiled, single)     # (tiles really were taken)
+    xr, wr, br = (t.detach().double().cpu().requires_grad_() for t in (x, w, b))
+    conv = F.conv2d if nd == 2 else F.conv3d
+    if mode == "constant":
+        want = conv(xr, wr, br, stride=stride, padding=padding, groups=g)
+    else:
+        want = conv(F.pad(xr, [q for p_ in reversed(padding) for q in (p_, p_)], mode=mode), wr, br, stride=stride, groups=g)
+    want.backward(gy.double().cpu())
+    assert _rel(y, want) < REL_TOL and _rel(y_single, want) < REL_TOL and _rel(y, y_single) < 5e-6
+    assert _rel(x.grad, xr.grad) < REL_TOL and _rel(w.grad, wr.grad) < REL_TOL and _rel(b.grad, br.grad) < REL_TOL

@@ -497,3 +497,44 @@ def test_rows_just_past_a_power_of_two_run_in_tiles_and_match_torch(case, monkey
     want.backward(gy.double().cpu())
     assert _rel(y, want) < REL_TOL and _rel(y_single, want) < REL_TOL and _rel(y, y_single) < 5e-6
     assert _rel(x.grad, xr.grad) < REL_TOL and _rel(w.grad, wr.grad) < REL_TOL and _rel(b.grad, br.grad) < REL_TOL
+
+
+@pytest.mark.parametrize("nd", [1, 2, 3])
+def test_a_whole_training_step_replays_from_a_hip_graph(nd):
+    """Forward + backward (dX, dW, db) of a module captured into ONE HIP graph after a warm-up step (plans, tables and the
+    allocator's blocks exist by then) and replayed on new data: the gradients of the replay equal an eager step's."""
+    from fft_conv_pytorch_amd import FFTConv1d, FFTConv2d, FFTConv3d
+    cls, size, k = {1: (FFTConv1d, (5000,), 129), 2: (FFTConv2d, (70, 150), (5, 7)), 3: (FFTConv3d, (20, 30, 70), 3)}[nd]
+    torch.manual_seed(10 + nd)
+    layer = cls(8, 8, k, padding=1, stride=1).to(DEV)
+    x_static = torch.randn(2, 8, *size, device=DEV, requires_grad=True)
+
+    def step():
+        layer.zero_grad(set_to_none=False)
+        if x_static.grad is not None:
+            x_static.grad.zero_()
+        loss = (layer(x_static) ** 2).sum()
+        loss.backward()
+
+    # warm-up on a side stream (torch's capture rule), grads allocated once so the graph writes into fixed buffers
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream(DEV).wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    new = torch.randn_like(x_static)
+    with torch.no_grad():
+        x_static.copy_(new)
+    graph.replay()
+    torch.cuda.synchronize()
+    got = [layer.weight.grad.clone(), layer.bias.grad.clone(), x_static.grad.clone()]
+    step()                                              # the same data, eagerly
+    torch.cuda.synchronize()
+    want = [layer.weight.grad, layer.bias.grad, x_static.grad]
+    for g_, w_ in zip(got, want):
+        assert _rel(g_, w_) < 1e-6

@@ -113,6 +113,30 @@ def ref_step(i):
 report("forward + backward, this library (autograd.Function)", timed(ours_step, args.iters), n_out, bwd_bytes)
 report("forward + backward, reference algorithm via torch.fft autograd, same GPU", timed(ref_step, args.iters), n_out, bwd_bytes)
 
+# the same with a materialised output gradient (what a following layer hands back) instead of .sum(): without the harness's
+# loss reduction and the copy that makes its broadcast gradient contiguous
+gys = [torch.randn(B, C, Lout, device=dev) for _ in range(3)]
+
+
+def ours_step_gy(i):
+    x = xr[i % 3]
+    x.grad = None
+    conv.zero_grad(set_to_none=True)
+    conv(x).backward(gys[i % 3])
+
+
+def ref_step_gy(i):
+    x = xr[i % 3]
+    x.grad = None
+    wr.grad = None
+    br.grad = None
+    rfft_conv(x, wr, br).backward(gys[i % 3])
+
+
+report("forward + backward from a given output gradient, this library", timed(ours_step_gy, args.iters), n_out, bwd_bytes)
+report("forward + backward from a given output gradient, reference algorithm via torch.fft autograd, same GPU",
+       timed(ref_step_gy, args.iters), n_out, bwd_bytes)
+
 # transposed convolution forward + backward (differentiable since round 2): dX is a forward plan, dW the weight gradient
 # with the roles of signal and gradient swapped
 gr = [g.clone().requires_grad_(True) for g in gs[:3]]

@@ -743,10 +743,12 @@ static int plan_nd(fc_plan* p) {
     // Measured (scripts/experiments/time_rows2d.py, profiles/r03_experiments.md block 10): 5-13 % faster than the LDS column
     // pass on large images with y kernels up to ~25 taps (B16 512^2 k3..k23, B2 1024^2 k7), level at k31 (a 64-point tile then
     // keeps 34 samples), 8-10 % slower on small problems (B4 256^2) -- taken from 2^20 intermediate samples per channel and
-    // 25 dilated taps down; FFTCONV_PLANES=2 takes it wherever it is possible (tests), 0 never.
+    // 25 dilated taps down (33 where the LDS pass would need several tiles); FFTCONV_PLANES=2 takes it wherever it is possible (tests), 0 never.
     if (nd == 2) {
       const int knob = env ? atoi(env) : 1;
-      const bool big = (int64_t)d.batch * p->Sp[0] * p->Fxt >= ((int64_t)1 << 20) && p->kd[0] <= 25;
+      // (26-33 taps: level with ONE 512-point tile of the LDS column pass -- cfgB -- but ahead of several of them:
+      //  B16 512^2 k31 'same' 341 us against 439)
+      const bool big = (int64_t)d.batch * p->Sp[0] * p->Fxt >= ((int64_t)1 << 20) && (p->kd[0] <= 25 || p->need[0] > 512);
       planes_ok = knob != 0 && (big || knob == 2) && !p->swap && t64 && t64->colz && p->CB == 8 && !p->accumulate &&
                   p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) && p->Fx % 16 == 0 &&
                   (int64_t)4 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) * p->Fxt * 8 < ((int64_t)1 << 31);

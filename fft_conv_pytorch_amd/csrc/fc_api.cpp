@@ -725,6 +725,30 @@ static int plan_nd(fc_plan* p) {
     }
     if (p->nyt == 1) p->Sp[1] = std::min(p->Sp[1], p->tm->T);    // (rows past the transform are zero padding: not produced)
   }
+  // 3-D planes larger than 64 x 64 after padding: cut into overlap-save tiles of 64 x 64 so that the plane-major pipeline
+  // (below) still applies -- each tile is one workgroup of planes_fwd / planes_inv and one block of 2048 columns of colz.
+  // Measured against the separable passes with the planner's own x / y tiles (profiles/r03_experiments.md block 12).
+  if (nd == 3 && !getenv("FFTCONV_XTILE") && !getenv("FFTCONV_YTILE") && !p->swap && !d.tile_hint) {
+    const char* pl = getenv("FFTCONV_PLANES");
+    const fc::TileImpl* t64 = find_tile(64);
+    const bool wide = p->tx->T > 64 || p->tm->T > 64 || p->nxt > 1 || p->nyt > 1;
+    if ((!pl || atoi(pl) != 0) && t64 && t64->colz && wide && p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && p->kd[1] <= 33 &&
+        p->kd[2] <= 33) {
+      const int64_t Vx = 64 - p->kd[2] + 1, Vy = 64 - p->kd[1] + 1;
+      const int64_t nx = p->need[2] <= 64 ? 1 : (p->Lf[2] + Vx - 1) / Vx, ny = p->need[1] <= 64 ? 1 : (p->Lf[1] + Vy - 1) / Vy;
+      // (taken while the tiles hold at most 1.5x the points of the separable plan's own transforms: at equal points the
+      //  pipeline measured 1.3-2.0x faster -- 64^3 k3 'same' 663 -> 507 us, 128^3 k5 'same' 772 -> 455, 200^3 k5 1,571 -> 787 --
+      //  at 2.25x, 128^3 k9 unpadded against single 128-point transforms, 14 % slower)
+      const int64_t sep_pts = (int64_t)p->nxt * p->tx->T * p->nyt * p->tm->T;
+      if (nx * ny <= 36 && nx * ny * 4096 * 2 <= sep_pts * 3) {
+        p->tx = t64; p->tm = t64;
+        p->nxt = (int)nx; p->Vx = nx == 1 ? p->Lf[2] : (int)Vx;
+        p->nyt = (int)ny; p->Vy = ny == 1 ? p->Lf[1] : (int)Vy;
+        p->Fx = 32; p->Fxt = p->nxt * p->Fx;
+        if (p->nyt == 1) p->Sp[1] = std::min(p->Sp[1], 64);
+      }
+    }
+  }
   // channel blocking of the fused (complex) pass: one sequence per channel
   p->nd_cob = std::min(p->CB, p->Cog);
   p->nd_Cog_pad = (int)round_up(p->Cog, p->nd_cob);
@@ -735,9 +759,10 @@ static int plan_nd(fc_plan* p) {
   {
     const char* env = getenv("FFTCONV_PLANES");
     const fc::TileImpl* t64 = find_tile(64);
-    planes_ok = (!env || atoi(env) != 0) && !p->swap && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 && p->nxt == 1 &&
-                p->nyt == 1 && p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) &&
-                (int64_t)2 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) < 65536;   // (32-bit offsets below 2 GiB per workgroup)
+    planes_ok = (!env || atoi(env) != 0) && !p->swap && nd == 3 && t64 && t64->colz && p->tx->T == 64 && p->tm->T == 64 &&
+                (int64_t)p->nxt * p->nyt <= 36 && (p->nxt == 1 || p->kd[2] <= 33) && (p->nyt == 1 || p->kd[1] <= 33) &&
+                p->CB == 8 && !p->accumulate && p->kd[0] <= 33 && (!d.tile_hint || d.tile_hint == 64) &&
+                (int64_t)2 * std::max(d.in_channels, d.out_channels) * std::max<int64_t>(p->Sp[0], p->out_sp[0]) * p->nxt * p->nyt < 65536;   // (32-bit offsets below 2 GiB per workgroup)
     // 2-D: the same column pass (one thread per 64-point sequence along y, lanes over neighbouring bin columns) between
     // row passes that keep the rows as they are -- taken under the same conditions on the y kernel and the channel blocks
     // Measured (scripts/experiments/time_rows2d.py, profiles/r03_experiments.md block 10): 5-13 % faster than the LDS column
@@ -814,8 +839,9 @@ static int plan_nd(fc_plan* p) {
   }
   p->planes = (planes_ok && best->T == 64) ? (nd == 3 ? 1 : 2) : 0;
   if (p->planes == 1) {
-    a_sig = B * Ci * (size_t)p->Sp[0] * fc::kPlCols;              // S[(b,ci)][zp][col]
-    b_sig = B * Co * (size_t)p->out_sp[0] * fc::kPlCols;          // O[(b,co)][z_out][col]
+    const size_t ntile = (size_t)p->nxt * p->nyt;
+    a_sig = B * Ci * (size_t)p->Sp[0] * ntile * fc::kPlCols;              // S[(b,ci)][zp][tile][col]
+    b_sig = B * Co * (size_t)p->out_sp[0] * ntile * fc::kPlCols;          // O[(b,co)][z_out][tile][col]
   }
   p->ws_a = std::max(a_sig, a_w);
   p->ws_b = std::max(b_sig, b_w);
@@ -1115,7 +1141,7 @@ int fc_plan_layout(const fc_plan* plan, int32_t layout[8]) {
 long long fc_debug_grid(const fc_plan* plan) {
   if (!plan || plan->d.dtype != FC_F32) return 0;
   if (plan->planes) {   // upper bound of colz's grid (one batch item per workgroup)
-    const long long ncol = plan->planes == 1 ? fc::kPlCols : plan->Fxt;
+    const long long ncol = plan->planes == 1 ? (long long)fc::kPlCols * plan->nxt * plan->nyt : plan->Fxt;
     return (long long)plan->d.batch * plan->ntiles * (plan->nd_Cog_pad / plan->nd_cob) * plan->d.groups * ((ncol / 16 + 7) / 8) * 8;
   }
   if (plan->nd != 1) {   // upper bound of the fused column pass's grid (one batch item per workgroup)
@@ -1366,6 +1392,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     f1.src = x; f1.dst = wsA; f1.twA = p.twx.twA; f1.twB = p.twx.twB;
     f1.mx = amap(2); f1.my = amap(1); f1.mz = amap(0);
     f1.SZ = (int)p.d.spatial[0]; f1.SY = (int)p.d.spatial[1]; f1.SX = (int)p.d.spatial[2]; f1.NZ = p.Sp[0];
+    f1.nxt = p.nxt; f1.nyt = p.nyt; f1.Vx = p.Vx; f1.Vy = p.Vy;
     FC_HIP(p.tile->planes_fwd(f1, B * Ci, st));
     fc::ColZArgs cz{};
     cz.src = wsA; cz.wspec = (const fc::f4*)w_hat; cz.dst = wsB;
@@ -1373,7 +1400,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     cz.cob = p.nd_cob; cz.n_ochunks = p.nd_Cog_pad / p.nd_cob;
     cz.NZ = p.Sp[0]; cz.NZo = (int)p.out_sp[0];
     cz.V = p.V; cz.ntiles = p.ntiles; cz.Lfull = p.Lfull; cz.stride = p.ostride[0];
-    cz.ncol = fc::kPlCols; cz.hcol = fc::kPlCols;
+    cz.ncol = fc::kPlCols * p.nxt * p.nyt; cz.hcol = fc::kPlCols;      // (the tiles of a plane share the spectrum's 2048 columns)
     cz.stamps = (unsigned long long*)stamps;        // profiling build of the column pass (scripts/phase_profile_nd.py)
     FC_HIP(p.tile->colz(cz, st));
     fc::PlaneInvArgs f3{};
@@ -1381,6 +1408,7 @@ int fc_forward_stamped(const fc_plan* plan, const float* x, const void* w_hat, c
     f3.NZo = (int)p.out_sp[0]; f3.Cout = Co;
     f3.NVy = p.Lf[1]; f3.sy = p.ostride[1]; f3.Yo = (int)p.out_sp[1];
     f3.NVx = p.Lf[2]; f3.sx = p.ostride[2]; f3.Xo = (int)p.out_sp[2];
+    f3.nxt = p.nxt; f3.nyt = p.nyt; f3.Vx = p.Vx; f3.Vy = p.Vy;
     FC_HIP(p.tile->planes_inv(f3, B * Co, st));
     return FC_OK;
   }

@@ -44,6 +44,9 @@ struct PlaneFwdArgs {
   AxisMap mx, my, mz;    // padding maps (functional.py:60-62 folded into the loads)
   int SZ, SY, SX;        // source extents
   int NZ;                // padded planes per image
+  int nxt, nyt, Vx, Vy;  // overlap-save tiles of the plane (padded plane larger than 64 x 64): tile (yt, xt) is the window of padded
+                         // positions [yt*Vy, yt*Vy + 64) x [xt*Vx, xt*Vx + 64); dst then holds nyt*nxt blocks of 2048 columns per plane
+  FastDiv d_nz, d_nt;    // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZ + zp)*ntile + tile
 };
 
 template <int NT_>
@@ -57,8 +60,12 @@ __global__ __launch_bounds__(kPlNT) void planes_fwd_kernel(const PlaneFwdArgs a)
   static_assert(64 * RP * 4 <= 32 * kPlPitch * 8, "row buffer fits the region");
   const BufRsrc twA = make_rsrc(a.twA, 8 * 8 * 8), twB = make_rsrc(a.twB, 8 * 8);
   const int tid = threadIdx.x, sq = tid >> 3, tseq = tid & 7;
-  const int img = blockIdx.x / a.NZ, zp = blockIdx.x - img * a.NZ;
-  f4* outp = reinterpret_cast<f4*>(a.dst + ((size_t)img * a.NZ + zp) * kPlCols);
+  unsigned qq;
+  const int tile = (int)fdivmod(blockIdx.x, a.d_nt, &qq);          // qq = img*NZ + zp
+  const int img = (int)fdiv(qq, a.d_nz), zp = (int)qq - img * a.NZ;
+  const int yt = tile / a.nxt, xt = tile - yt * a.nxt;
+  const int x0 = xt * a.Vx, y0 = yt * a.Vy;                         // padded position of this tile's corner
+  f4* outp = reinterpret_cast<f4*>(a.dst + (size_t)blockIdx.x * kPlCols);
   const int zs = axis_src(a.mz, zp);
   if (zs < 0) {                                            // a plane of padding zeros (workgroup-uniform)
     const f4 z = {0.f, 0.f, 0.f, 0.f};
@@ -79,19 +86,19 @@ __global__ __launch_bounds__(kPlNT) void planes_fwd_kernel(const PlaneFwdArgs a)
     if (a.mx.up == 1 && a.my.up == 1 && a.mx.mode == PAD_CONSTANT) {
       // zero padding, no spread (the usual case): a shift and a bounds test per element -- the general index map below is
       // a division and three mode branches per element, 17 times per thread: most of this kernel's instructions
-      const int xs = xp - a.mx.pad;
+      const int xs = x0 + xp - a.mx.pad;
       const bool xok = (unsigned)xs < (unsigned)a.SX;
-      const unsigned base = (unsigned)(((tid >> 6) - a.my.pad) * a.SX + xs) * 4u, step = (unsigned)(4 * a.SX) * 4u;
+      const unsigned base = (unsigned)((y0 + (tid >> 6) - a.my.pad) * a.SX + xs) * 4u, step = (unsigned)(4 * a.SX) * 4u;
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int ys = (tid >> 6) + 4 * u - a.my.pad;
+        const int ys = y0 + (tid >> 6) + 4 * u - a.my.pad;
         val[u] = buf_load_f32(pr, (xok && (unsigned)ys < (unsigned)a.SY) ? base + step * u : 0xFFFFFFFFu, 0);
       }
     } else {
-      const int xs = axis_src(a.mx, xp);
+      const int xs = axis_src(a.mx, x0 + xp);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
-        const int yp = (tid >> 6) + 4 * u;
+        const int yp = y0 + (tid >> 6) + 4 * u;
         const int ys = axis_src(a.my, yp);
         val[u] = buf_load_f32(pr, (ys >= 0 && xs >= 0) ? (unsigned)(ys * a.SX + xs) * 4u : 0xFFFFFFFFu, 0);
       }
@@ -171,6 +178,9 @@ struct PlaneInvArgs {
   int NZo, Cout;
   int NVy, sy, Yo;       // valid stride-1 rows, decimation, output rows
   int NVx, sx, Xo;
+  int nxt, nyt, Vx, Vy;  // overlap-save tiles of the plane (see PlaneFwdArgs): tile (yt, xt) yields the stride-1 samples
+                         // [yt*Vy, yt*Vy + Vy) x [xt*Vx, xt*Vx + Vx) of the plane; src holds nyt*nxt blocks of 2048 columns per plane
+  FastDiv d_nz, d_nt;    // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZo + zi)*ntile + tile
 };
 
 template <int NT_>
@@ -181,11 +191,20 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
   static_assert(64 * YP <= 32 * kPlPitch, "transposed rows fit the region");
   const BufRsrc twA = make_rsrc(a.twA, 8 * 8 * 8), twB = make_rsrc(a.twB, 8 * 8);
   const int tid = threadIdx.x, sq = tid >> 3, tseq = tid & 7;
-  const int img = blockIdx.x / a.NZo, zi = blockIdx.x - img * a.NZo;
+  unsigned qq;
+  const int tile = (int)fdivmod(blockIdx.x, a.d_nt, &qq);          // qq = img*NZo + zi
+  const int img = (int)fdiv(qq, a.d_nz);
+  const int yt = tile / a.nxt, xt = tile - yt * a.nxt;
+  // this tile's window of stride-1 samples and of output samples: local sample n is sample g0 + n of the plane's axis and,
+  // where that is a multiple of the stride, output (g0 + n)/s -- row / column (g0 + n)/s - o0 of this tile's output block
+  const int gy0 = yt * a.Vy, gx0 = xt * a.Vx;
+  const int NVy = min(a.Vy, a.NVy - gy0), NVx = min(a.Vx, a.NVx - gx0);
+  const int oy0 = (gy0 + a.sy - 1) / a.sy, ox0 = (gx0 + a.sx - 1) / a.sx;
+  const int Yo = NVy > 0 ? (gy0 + NVy - 1) / a.sy - oy0 + 1 : 0, Xo = NVx > 0 ? (gx0 + NVx - 1) / a.sx - ox0 + 1 : 0;
   f2 w[8];
   passA_twiddle_fetch<G>(w, tseq, twA);                    // one batch for both inverse passes, ahead of the plane
   {
-    const f4* inp = reinterpret_cast<const f4*>(a.src + ((size_t)img * a.NZo + zi) * kPlCols);
+    const f4* inp = reinterpret_cast<const f4*>(a.src + (size_t)blockIdx.x * kPlCols);
     f4 q[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) q[u] = inp[tid + kPlNT * u];
@@ -212,20 +231,20 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int n = tseq + 8 * k;
-      if (n < a.NVy) reg[n * YP + sq] = v[k];
+      if (n < NVy) reg[n * YP + sq] = v[k];
     }
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int n = tseq + 8 * k, yo = n / a.sy;
-      if (n < a.NVy && yo * a.sy == n) reg[yo * YP + sq] = v[k];
+      const int n = tseq + 8 * k, yo = (gy0 + n) / a.sy;
+      if (n < NVy && yo * a.sy == gy0 + n) reg[(yo - oy0) * YP + sq] = v[k];
     }
   }
   __syncthreads();
   // ---- x rows back: output rows 2sq (-> real part) and 2sq+1 (-> imaginary part) share one inverse transform
   // (odd-frequency bins: V[f] = Ya[f] + i Yb[f], V[63-f] = conj(Ya[f]) + i conj(Yb[f]), f < 32; rows_c2r)
   const int ra = 2 * sq, rb = ra + 1;
-  const bool has_a = ra < a.Yo, has_b = rb < a.Yo;
+  const bool has_a = ra < Yo, has_b = rb < Yo;
   static_for<0, 8>([&](auto ic) {
     constexpr int i1 = decltype(ic)::value;
     const int f = 8 * i1 + tseq, fs = i1 < 4 ? f : 63 - f;
@@ -251,30 +270,37 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
     });
   }
   __syncthreads();                                          // every exchange has been read: the region becomes the output plane
-  float* ob = reinterpret_cast<float*>(reg);                // [Yo][Xo]
+  float* ob = reinterpret_cast<float*>(reg);                // [Yo][Xo] of this tile
   if (a.sx == 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int n = tseq + 8 * k;
-      if (n < a.NVx) {
-        if (has_a) ob[ra * a.Xo + n] = v[k].x + b;
-        if (has_b) ob[rb * a.Xo + n] = v[k].y + b;
+      if (n < NVx) {
+        if (has_a) ob[ra * Xo + n] = v[k].x + b;
+        if (has_b) ob[rb * Xo + n] = v[k].y + b;
       }
     }
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int n = tseq + 8 * k, xo = n / a.sx;
-      if (n < a.NVx && xo * a.sx == n) {
-        if (has_a) ob[ra * a.Xo + xo] = v[k].x + b;
-        if (has_b) ob[rb * a.Xo + xo] = v[k].y + b;
+      const int n = tseq + 8 * k, xo = (gx0 + n) / a.sx;
+      if (n < NVx && xo * a.sx == gx0 + n) {
+        if (has_a) ob[ra * Xo + xo - ox0] = v[k].x + b;
+        if (has_b) ob[rb * Xo + xo - ox0] = v[k].y + b;
       }
     }
   }
   __syncthreads();
-  float* op = a.dst + ((size_t)img * a.NZo + zi) * a.Yo * a.Xo;
-  const int total = a.Yo * a.Xo;
-  for (int idx = tid; idx < total; idx += kPlNT) op[idx] = ob[idx];
+  float* op = a.dst + (size_t)qq * a.Yo * a.Xo;             // the (b, co, z_out) plane
+  const int total = Yo * Xo;
+  if (a.nxt * a.nyt == 1) {                                 // (the whole plane: one contiguous run)
+    for (int idx = tid; idx < total; idx += kPlNT) op[idx] = ob[idx];
+  } else {
+    for (int idx = tid; idx < total; idx += kPlNT) {
+      const int r = idx / Xo, c = idx - r * Xo;
+      op[(size_t)(oy0 + r) * a.Xo + ox0 + c] = ob[idx];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------ colz

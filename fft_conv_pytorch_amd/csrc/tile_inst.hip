@@ -349,15 +349,26 @@ hipError_t dense_spec_dispatch(const DenseSpecArgs& a, hipStream_t st) {
 #if FC_P == 8 && FC_S == 1
 // plane-major 3-D pipeline: 64-point transforms on all three axes
 hipError_t planes_fwd_dispatch(const PlaneFwdArgs& a, int n_images, hipStream_t st) {
-  const long long grid = (long long)n_images * a.NZ;
+  PlaneFwdArgs b = a;
+  if (b.nxt < 1) b.nxt = 1;
+  if (b.nyt < 1) b.nyt = 1;
+  const long long ntile = (long long)b.nxt * b.nyt;
+  const long long grid = (long long)n_images * a.NZ * ntile;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(planes_fwd_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
+  b.d_nz = make_fastdiv((unsigned)a.NZ); b.d_nt = make_fastdiv((unsigned)ntile);
+  hipLaunchKernelGGL(planes_fwd_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, b);
   return hipGetLastError();
 }
 hipError_t planes_inv_dispatch(const PlaneInvArgs& a, int n_images, hipStream_t st) {
-  const long long grid = (long long)n_images * a.NZo;
+  PlaneInvArgs b = a;
+  if (b.nxt < 1) b.nxt = 1;
+  if (b.nyt < 1) b.nyt = 1;
+  if (b.nxt * b.nyt == 1) { b.Vx = a.NVx > 0 ? a.NVx : 1; b.Vy = a.NVy > 0 ? a.NVy : 1; }    // (one tile: the whole window)
+  const long long ntile = (long long)b.nxt * b.nyt;
+  const long long grid = (long long)n_images * a.NZo * ntile;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, a);
+  b.d_nz = make_fastdiv((unsigned)a.NZo); b.d_nt = make_fastdiv((unsigned)ntile);
+  hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, b);
   return hipGetLastError();
 }
 template <int NB, bool STAMPS, int DIAG, int NCOLC>

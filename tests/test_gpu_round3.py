@@ -30,6 +30,10 @@ PLANE_CASES = [
     (2, 6, 6, 1, (17, 33, 20), (2, 3, 3), (1, 2, 1), 1, 1, "replicate"),
     (2, 8, 8, 1, (150, 40, 40), (9, 3, 3), 1, 0, 1, "constant"),             # several overlap-save tiles along z
     (1, 8, 8, 1, (100, 20, 20), (33, 3, 3), (3, 1, 1), 4, 1, "constant"),    # longest z kernel of the path, z stride
+    (2, 8, 8, 1, (40, 100, 130), (3, 5, 5), 1, 2, 1, "constant"),            # planes larger than 64 x 64: 2 x 3 overlap-save tiles per plane
+    (1, 8, 8, 1, (64, 64, 64), (3, 3, 3), 1, 1, 1, "constant"),              # 'same' padding on 64^3: 66 samples = two tiles on every axis
+    (2, 8, 16, 1, (30, 70, 90), (5, 3, 7), (1, 2, 3), (2, 1, 3), 1, "reflect"),   # tiles with strides and index-map padding
+    (1, 8, 8, 1, (20, 200, 70), (3, 9, 3), 1, (1, 0, 4), (1, 2, 1), "circular"),  # four y tiles, dilated y kernel
 ]
 
 

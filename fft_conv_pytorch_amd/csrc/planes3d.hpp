@@ -46,7 +46,7 @@ struct PlaneFwdArgs {
   int NZ;                // padded planes per image
   int nxt, nyt, Vx, Vy;  // overlap-save tiles of the plane (padded plane larger than 64 x 64): tile (yt, xt) is the window of padded
                          // positions [yt*Vy, yt*Vy + 64) x [xt*Vx, xt*Vx + 64); dst then holds nyt*nxt blocks of 2048 columns per plane
-  FastDiv d_nz, d_nt;    // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZ + zp)*ntile + tile
+  FastDiv d_nz, d_nt, d_nx;   // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZ + zp)*ntile + tile, tile = yt*nxt + xt
 };
 
 template <int NT_>
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kPlNT) void planes_fwd_kernel(const PlaneFwdArgs a)
   unsigned qq;
   const int tile = (int)fdivmod(blockIdx.x, a.d_nt, &qq);          // qq = img*NZ + zp
   const int img = (int)fdiv(qq, a.d_nz), zp = (int)qq - img * a.NZ;
-  const int yt = tile / a.nxt, xt = tile - yt * a.nxt;
+  const int yt = (int)fdiv((unsigned)tile, a.d_nx), xt = tile - yt * a.nxt;
   const int x0 = xt * a.Vx, y0 = yt * a.Vy;                         // padded position of this tile's corner
   f4* outp = reinterpret_cast<f4*>(a.dst + (size_t)blockIdx.x * kPlCols);
   const int zs = axis_src(a.mz, zp);
@@ -180,7 +180,7 @@ struct PlaneInvArgs {
   int NVx, sx, Xo;
   int nxt, nyt, Vx, Vy;  // overlap-save tiles of the plane (see PlaneFwdArgs): tile (yt, xt) yields the stride-1 samples
                          // [yt*Vy, yt*Vy + Vy) x [xt*Vx, xt*Vx + Vx) of the plane; src holds nyt*nxt blocks of 2048 columns per plane
-  FastDiv d_nz, d_nt;    // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZo + zi)*ntile + tile
+  FastDiv d_nz, d_nt, d_nx;   // unit map of the launch (filled by the dispatcher): blockIdx = (img*NZo + zi)*ntile + tile, tile = yt*nxt + xt
 };
 
 template <int NT_>
@@ -194,13 +194,15 @@ __global__ __launch_bounds__(kPlNT) void planes_inv_kernel(const PlaneInvArgs a)
   unsigned qq;
   const int tile = (int)fdivmod(blockIdx.x, a.d_nt, &qq);          // qq = img*NZo + zi
   const int img = (int)fdiv(qq, a.d_nz);
-  const int yt = tile / a.nxt, xt = tile - yt * a.nxt;
+  const int yt = (int)fdiv((unsigned)tile, a.d_nx), xt = tile - yt * a.nxt;
   // this tile's window of stride-1 samples and of output samples: local sample n is sample g0 + n of the plane's axis and,
   // where that is a multiple of the stride, output (g0 + n)/s -- row / column (g0 + n)/s - o0 of this tile's output block
   const int gy0 = yt * a.Vy, gx0 = xt * a.Vx;
   const int NVy = min(a.Vy, a.NVy - gy0), NVx = min(a.Vx, a.NVx - gx0);
-  const int oy0 = (gy0 + a.sy - 1) / a.sy, ox0 = (gx0 + a.sx - 1) / a.sx;
-  const int Yo = NVy > 0 ? (gy0 + NVy - 1) / a.sy - oy0 + 1 : 0, Xo = NVx > 0 ? (gx0 + NVx - 1) / a.sx - ox0 + 1 : 0;
+  // (stride 1 -- the usual case -- without the emulated divisions: they are uniform but run on the vector pipeline)
+  int oy0 = gy0, ox0 = gx0, Yo = max(NVy, 0), Xo = max(NVx, 0);
+  if (a.sy != 1) { oy0 = (gy0 + a.sy - 1) / a.sy; Yo = NVy > 0 ? (gy0 + NVy - 1) / a.sy - oy0 + 1 : 0; }
+  if (a.sx != 1) { ox0 = (gx0 + a.sx - 1) / a.sx; Xo = NVx > 0 ? (gx0 + NVx - 1) / a.sx - ox0 + 1 : 0; }
   f2 w[8];
   passA_twiddle_fetch<G>(w, tseq, twA);                    // one batch for both inverse passes, ahead of the plane
   {

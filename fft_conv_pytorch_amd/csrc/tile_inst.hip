@@ -355,7 +355,7 @@ hipError_t planes_fwd_dispatch(const PlaneFwdArgs& a, int n_images, hipStream_t 
   const long long ntile = (long long)b.nxt * b.nyt;
   const long long grid = (long long)n_images * a.NZ * ntile;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  b.d_nz = make_fastdiv((unsigned)a.NZ); b.d_nt = make_fastdiv((unsigned)ntile);
+  b.d_nz = make_fastdiv((unsigned)a.NZ); b.d_nt = make_fastdiv((unsigned)ntile); b.d_nx = make_fastdiv((unsigned)b.nxt);
   hipLaunchKernelGGL(planes_fwd_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, b);
   return hipGetLastError();
 }
@@ -367,7 +367,7 @@ hipError_t planes_inv_dispatch(const PlaneInvArgs& a, int n_images, hipStream_t 
   const long long ntile = (long long)b.nxt * b.nyt;
   const long long grid = (long long)n_images * a.NZo * ntile;
   if (grid <= 0 || grid > 0x7fffffffLL) return hipErrorInvalidValue;
-  b.d_nz = make_fastdiv((unsigned)a.NZo); b.d_nt = make_fastdiv((unsigned)ntile);
+  b.d_nz = make_fastdiv((unsigned)a.NZo); b.d_nt = make_fastdiv((unsigned)ntile); b.d_nx = make_fastdiv((unsigned)b.nxt);
   hipLaunchKernelGGL(planes_inv_kernel<kPlNT>, dim3((unsigned)grid), dim3(kPlNT), 0, st, b);
   return hipGetLastError();
 }
